@@ -1,0 +1,286 @@
+/*
+ * rt_abi.h — C ABI of the MI355X-native render path (Camera::render -> World::color_at).
+ *
+ * The reference crate (ashcolecarr/Ray-Tracer, Rust) has no FFI layer; this header is the
+ * boundary its host side binds (see INTEGRATION.md for the Rust `extern "C"` block).  The
+ * host keeps World/Shape/Material/Camera and scene construction; at render time it flattens
+ * the scene into the structure-of-arrays tables below and calls rt_render().  Everything on
+ * the device side (ray generation, scene traversal, intersection, CSG filtering,
+ * prepare_computations, shadows, Phong + patterns, reflection/refraction/Schlick) is
+ * hand-written HIP for gfx950 behind these entry points.
+ *
+ * Conventions
+ *   - All floating point is IEEE f64, ids and indices are int32 (reference: src/lib.rs:46,64-66).
+ *   - Matrices are 4x4 row-major, 16 doubles.  Every inverse handed over must be affine:
+ *     last row exactly (0,0,0,1) (sign of the zeros is ignored).  That is what
+ *     Matrix::inverse (src/matrix.rs:124-154) yields for every transform built from
+ *     src/transformation.rs.  rt_scene_create returns RT_ERR_UNSUPPORTED otherwise.
+ *   - Points/vectors are 3 doubles; the implied w is 1 for points and 0 for vectors.
+ *   - The caller owns every input array for the duration of the call; the library copies
+ *     what it keeps.  The caller allocates every output.  No ownership crosses the boundary
+ *     except the opaque rt_scene handle, which only rt_scene_destroy frees.
+ *   - Return value 0 = RT_OK, negative = error class; rt_last_error() gives the text
+ *     (thread-local).  Nothing unwinds across the boundary.
+ *   - The reference is single-threaded with process-global registries (src/lib.rs:46-54);
+ *     a given rt_scene handle must be used from one host thread at a time.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* error classes */
+#define RT_OK 0
+#define RT_ERR_BAD_ARG (-1)      /* null pointer, negative count, index out of range          */
+#define RT_ERR_UNSUPPORTED (-2)  /* non-affine transform, non-invertible camera, ...          */
+#define RT_ERR_HIP (-3)          /* a HIP runtime call failed (text has hipGetErrorString)    */
+#define RT_ERR_NO_DEVICE (-4)    /* no gfx950 device / device index out of range              */
+#define RT_ERR_OVERFLOW (-5)     /* a bounded per-ray scratch list overflowed (see flags too) */
+
+/* node kinds — enum Shape, src/shape.rs:25-37 (TestShape has no device counterpart) */
+#define RT_SPHERE 0          /* src/sphere.rs          */
+#define RT_PLANE 1           /* src/plane.rs           */
+#define RT_CUBE 2            /* src/cube.rs            */
+#define RT_CYLINDER 3        /* src/cylinder.rs        */
+#define RT_CONE 4            /* src/cone.rs            */
+#define RT_TRIANGLE 5        /* src/triangle.rs        */
+#define RT_SMOOTH_TRIANGLE 6 /* src/smooth_triangle.rs */
+#define RT_GROUP 7           /* src/group.rs           */
+#define RT_CSG 8             /* src/csg.rs             */
+
+/* CSG operation — the `operation: String` of src/csg.rs:18; any other string is UNKNOWN,
+ * for which intersection_allowed returns false (src/csg.rs:102). */
+#define RT_CSG_UNION 0
+#define RT_CSG_INTERSECTION 1
+#define RT_CSG_DIFFERENCE 2
+#define RT_CSG_UNKNOWN 3
+
+/* pattern kinds — enum Pattern, src/pattern.rs:7-14 */
+#define RT_PAT_STRIPED 0
+#define RT_PAT_GRADIENT 1
+#define RT_PAT_RING 2
+#define RT_PAT_CHECKERED 3
+#define RT_PAT_RING_GRADIENT 4
+#define RT_PAT_TEST 5
+
+/* columns of material_params — struct Material, src/material.rs:11-21 */
+#define RT_MAT_R 0
+#define RT_MAT_G 1
+#define RT_MAT_B 2
+#define RT_MAT_AMBIENT 3
+#define RT_MAT_DIFFUSE 4
+#define RT_MAT_SPECULAR 5
+#define RT_MAT_SHININESS 6
+#define RT_MAT_REFLECTIVE 7
+#define RT_MAT_TRANSPARENCY 8
+#define RT_MAT_REFRACTIVE_INDEX 9
+#define RT_MAT_STRIDE 10
+
+/* per-pixel / per-ray flag bits */
+#define RT_FLAG_REF_PANIC_UV 1u  /* reference would panic: SmoothTriangle::normal_at unwraps the u/v of
+                                    intersections[0], which is not a smooth-triangle hit
+                                    (src/intersection.rs:40, src/smooth_triangle.rs:98-100); the hit's own
+                                    u,v were used instead */
+#define RT_FLAG_NAN_T 2u         /* a NaN t reached a sort: reference panics in partial_cmp().unwrap()
+                                    (src/world.rs:52, src/group.rs:59, src/csg.rs:71)                    */
+#define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list (CSG scratch / n1-n2 container walk) overflowed */
+
+/*
+ * Flattened scene.  `nodes` is the intersection tree exactly as World::intersect_world walks it
+ * (src/world.rs:46-55): world.objects in order, each subtree in depth-first pre-order, Group
+ * children in `shapes` order (src/group.rs:54-57), CSG left subtree then right subtree
+ * (src/csg.rs:67-70).  The node index therefore IS the reference's emission order, which is what
+ * the stable sorts fall back to on equal t.
+ */
+typedef struct rt_scene_desc {
+    int32_t abi_version; /* RT_ABI_VERSION */
+
+    /* ---- nodes: one per Shape value in the tree (src/shape.rs:25-37) ---- */
+    int32_t n_nodes;
+    const int32_t* node_kind;        /* RT_SPHERE ... RT_CSG                                           */
+    const int32_t* node_object_id;   /* Shape::get_id (ids start at 1, src/lib.rs:46)                  */
+    const int32_t* node_parent;      /* tree parent node index, -1 for world.objects entries           */
+    const int32_t* node_subtree_end; /* one past the last descendant (pre-order skip pointer)          */
+    const int32_t* node_xform;       /* index into xform_*: inverse of this node's own transform, as
+                                        Shape::intersect uses it (src/shape.rs:75)                     */
+    const int32_t* node_ancestor;    /* leaves: index into ancestor_* of the registry entry of the
+                                        shape's `parent` id (src/shape.rs:394-420), -1 if None         */
+    const int32_t* node_material;    /* leaves: index into material_*; the ROOT ancestor's material
+                                        (Shape::get_material, src/shape.rs:163-184)                    */
+    const uint8_t* node_casts_shadow; /* the leaf's own flag (src/shape.rs:209-222)                    */
+    const int32_t* node_eq_class;    /* leaves: two nodes compare equal under Shape::eq iff their
+                                        classes are equal and >= 0; -1 = not even equal to itself
+                                        (NaN/inf in an epsilon-compared field, e.g. an unbounded
+                                        cylinder: src/cylinder.rs:26-33)                               */
+    const int32_t* node_param;       /* GROUP -> group index, CSG -> csg index, CYLINDER/CONE -> conic
+                                        index, TRIANGLE/SMOOTH_TRIANGLE -> triangle index, else -1     */
+
+    /* ---- transforms ---- */
+    int32_t n_xforms;
+    const double* xform_inverse;           /* [n_xforms][16]  transform.inverse()                       */
+    const double* xform_inverse_transpose; /* [n_xforms][16]  transform.inverse().transpose()           */
+
+    /* ---- registry chain used by world_to_object / normal_to_world (src/lib.rs:47-49) ---- */
+    int32_t n_ancestors;
+    const int32_t* ancestor_xform;  /* index into xform_*                                               */
+    const int32_t* ancestor_parent; /* next entry up the chain, -1 at the root                          */
+
+    /* ---- Group gate boxes: Group::bounds_of in group-local space (src/group.rs:86-95) ---- */
+    int32_t n_groups;
+    const double* group_box; /* [n_groups][6] = min.x,min.y,min.z,max.x,max.y,max.z (may be +-inf)      */
+
+    /* ---- CSG ---- */
+    int32_t n_csg;
+    const int32_t* csg_op; /* RT_CSG_*                                                                  */
+
+    /* ---- cylinders and cones (src/cylinder.rs:15-24, src/cone.rs:15-24) ---- */
+    int32_t n_conics;
+    const double* conic_minimum;
+    const double* conic_maximum;
+    const uint8_t* conic_closed;
+
+    /* ---- triangles (src/triangle.rs:12-24, src/smooth_triangle.rs:12-27) ---- */
+    int32_t n_triangles;
+    const double* tri_p1;     /* [n_triangles][3] point1                                               */
+    const double* tri_e1;     /* [n_triangles][3] edge_vector1 = p2 - p1                               */
+    const double* tri_e2;     /* [n_triangles][3] edge_vector2 = p3 - p1                               */
+    const double* tri_normal; /* [n_triangles][3] normalize(e2 x e1)                                   */
+    const int32_t* tri_smooth; /* index into smooth_* or -1 for a flat triangle                        */
+    int32_t n_smooth;
+    const double* smooth_n1; /* [n_smooth][3] normal_vector1..3                                        */
+    const double* smooth_n2;
+    const double* smooth_n3;
+
+    /* ---- materials and patterns (src/material.rs, src/pattern.rs) ---- */
+    int32_t n_materials;
+    const double* material_params;   /* [n_materials][RT_MAT_STRIDE]                                   */
+    const int32_t* material_pattern; /* index into pattern_* or -1                                     */
+    int32_t n_patterns;
+    const int32_t* pattern_kind;   /* RT_PAT_*                                                         */
+    const double* pattern_a;       /* [n_patterns][3]                                                  */
+    const double* pattern_b;       /* [n_patterns][3]                                                  */
+    const double* pattern_inverse; /* [n_patterns][16] pattern transform.inverse() (src/pattern.rs:25) */
+
+    /* ---- lights (src/light.rs:5-20), in world.lights order ---- */
+    int32_t n_lights;
+    const double* light_position;  /* [n_lights][3] */
+    const double* light_intensity; /* [n_lights][3] */
+} rt_scene_desc;
+
+/* struct Camera after Camera::new, src/camera.rs:10-35 */
+typedef struct rt_camera_desc {
+    int32_t hsize;
+    int32_t vsize;
+    int32_t invertible; /* transform.inverse().is_some(); 0 -> RT_ERR_UNSUPPORTED (src/camera.rs:44-46) */
+    int32_t _pad;
+    double inverse[16]; /* transform.inverse() */
+    double half_width;
+    double half_height;
+    double pixel_size;
+} rt_camera_desc;
+
+typedef struct rt_render_opts {
+    int32_t max_depth;    /* `remaining` passed to color_at; Camera::render uses DEFAULT_RECURSION = 5
+                             (src/camera.rs:68, src/lib.rs:41)                                          */
+    int32_t rank;         /* tile shard of this call, 0 <= rank < n_ranks                               */
+    int32_t n_ranks;      /* 1 = whole frame                                                            */
+    int32_t want_counters; /* 1 = also run the instrumented traversal and fill rt_stats.work_*          */
+    void* stream;         /* hipStream_t to enqueue on, NULL = the library's own stream                 */
+} rt_render_opts;
+
+typedef struct rt_stats {
+    /* rays actually traced, by class (BASELINE.md ray accounting) */
+    int64_t rays_primary;
+    int64_t rays_reflect;
+    int64_t rays_refract;
+    int64_t rays_shadow;
+    int64_t rays_container; /* extra list-collection passes for the n1/n2 walk (not counted as rays) */
+    int64_t shaded_nodes;   /* nodes of the recursion tree that hit something                         */
+    int32_t levels;         /* recursion levels that held at least one ray                            */
+    int32_t _pad;
+    /* device time per kernel class, ms, measured with HIP events on the launch stream */
+    double ms_total;
+    double ms_raygen;
+    double ms_trace;   /* closest-hit traversal launches  */
+    double ms_shadow;  /* shadow traversal launches       */
+    double ms_collect; /* container-list launches         */
+    double ms_shade;   /* prepare + lighting + spawn      */
+    double ms_resolve; /* bottom-up colour resolve        */
+    int32_t n_trace_launches;
+    int32_t n_shadow_launches;
+    /* algorithmic work counted by the instrumented traversal (want_counters = 1), closest-hit
+     * and shadow launches together; SURVEY.md section 8(d) constants turn these into flops/bytes */
+    int64_t work_xforms;      /* ray transforms (2 mat-vec each)            */
+    int64_t work_box_tests;   /* acceleration-BVH box tests                 */
+    int64_t work_gate_tests;  /* reference Group gate tests (bound.rs:85)   */
+    int64_t work_tri_tests;   /* triangle tests entered                     */
+    int64_t work_tri_det_rej; /*   ... rejected at |det| < EPSILON          */
+    int64_t work_tri_u_rej;   /*   ... rejected at u                        */
+    int64_t work_tri_v_rej;   /*   ... rejected at v                        */
+    int64_t work_prim_tests[5]; /* sphere, plane, cube, cylinder, cone      */
+    int64_t work_bvh_nodes;   /* BVH nodes fetched                          */
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque: device-resident tables + acceleration structure + queues */
+
+/* Number of usable HIP devices (0 when none / no driver).  No reference counterpart: the crate is CPU-only. */
+int rt_device_count(void);
+
+/* Copy the flattened scene to device `device`, build the (non-semantic, conservative) acceleration BVH over
+ * real triangle bounds, and return a handle.  Replaces the per-render use the reference makes of World
+ * (src/world.rs:15-18) and of the global registries (src/lib.rs:46-54) — all resolved by the flattener. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+
+/* Free everything rt_scene_create and later renders allocated for this scene. */
+void rt_scene_destroy(rt_scene* scene);
+
+/* Camera::render (src/camera.rs:62-74): full frame, host output buffers.
+ *   rgb_out     [vsize*hsize*3] row-major f64 RGB; last row and last column stay 0.0 (src/camera.rs:65-66)
+ *   hit_id_out  nullable [vsize*hsize] object id of the primary hit, 0 = miss
+ *   flags_out   nullable [vsize*hsize] RT_FLAG_* bits (OR over the pixel's whole ray tree)
+ *   stats_out   nullable */
+int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
+              int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats_out);
+
+/* Number of pixels shard `rank` of `n_ranks` renders (8x8-pixel tiles of the (hsize-1)x(vsize-1) domain dealt
+ * round-robin).  Negative on bad arguments. */
+int64_t rt_shard_pixel_count(const rt_camera_desc* camera, int32_t rank, int32_t n_ranks);
+
+/* One shard of Camera::render with DEVICE output pointers (for one-process-per-GPU drivers that gather the
+ * shards with RCCL).  d_rgb_out [count*3], d_hit_id_out nullable [count], d_flags_out nullable [count], in
+ * shard-local pixel order; count = rt_shard_pixel_count().  Asynchronous on opts->stream when stats_out is NULL. */
+int rt_render_shard(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_out,
+                    int32_t* d_hit_id_out, uint8_t* d_flags_out, rt_stats* stats_out);
+
+/* Scatter gathered shards (concatenated in rank order, DEVICE memory, on `scene`'s device) into a full
+ * row-major frame, zero elsewhere.  d_rgb_frame [vsize*hsize*3] device.  d_hit_id_* nullable. */
+int rt_assemble(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const double* d_rgb_shards,
+                const int32_t* d_hit_id_shards, double* d_rgb_frame, int32_t* d_hit_id_frame, void* stream);
+
+/* World::color_at (src/world.rs:81-90) for a batch of arbitrary rays, host buffers.
+ *   origins, directions [n_rays][3]; rgb_out [n_rays][3]; hit_id_out / flags_out nullable [n_rays]. */
+int rt_color_at(rt_scene* scene, int64_t n_rays, const double* origins, const double* directions, int32_t remaining,
+                double* rgb_out, int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats_out);
+
+/* World::intersect_world (src/world.rs:46-55) for a batch of rays: the sorted intersection list.
+ *   count_out [n_rays] true list length (may exceed max_hits, then only the first max_hits are stored);
+ *   t_out / object_id_out [n_rays][max_hits]. */
+int rt_intersect_world(rt_scene* scene, int64_t n_rays, const double* origins, const double* directions,
+                       int32_t max_hits, int32_t* count_out, double* t_out, int32_t* object_id_out);
+
+/* World::is_shadowed (src/world.rs:92-107) for a batch of points: out [n_points][n_lights], 1 = shadowed. */
+int rt_is_shadowed(rt_scene* scene, int64_t n_points, const double* points, uint8_t* out);
+
+/* Text of the last error on this thread ("" if none). */
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,97 @@
+/*
+ * rt_host.h — C handle API over the C++ host mirror (ray-tracer_amd/host/ray_tracer.hpp).
+ *
+ * This is NOT the hot-path boundary (that is rt_abi.h).  It exists so that non-C++ callers — the Python test
+ * suite and bench.py through ctypes — can build scenes with the reference crate's own vocabulary
+ * (Shape/Group/CSG/Material/Pattern/World/Camera, parse_obj_file/obj_to_group) and obtain the flattened
+ * rt_scene_desc the hot path consumes.  Handles are small non-negative ints; every function returns a
+ * negative RT_ERR_* code on failure with the text in rt_last_error().  A Rust `panic!` at the same place in the
+ * reference is reported as RT_ERR_UNSUPPORTED with the panic text.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- src/transformation.rs, src/matrix.rs: 4x4 row-major, 16 doubles ---- */
+void rth_identity(double* out16);
+void rth_translate(double x, double y, double z, double* out16);                         /* transformation.rs:10 */
+void rth_scale(double x, double y, double z, double* out16);                             /* transformation.rs:19 */
+void rth_rotate(int axis /*0=X,1=Y,2=Z*/, double radians, double* out16);                /* transformation.rs:28 */
+void rth_shear(double xy, double xz, double yx, double yz, double zx, double zy, double* out16); /* :55 */
+void rth_view_transform(const double* from3, const double* to3, const double* up3, double* out16); /* :67 */
+void rth_matmul(const double* a16, const double* b16, double* out16);                    /* matrix.rs:171 */
+int rth_inverse(const double* m16, double* out16); /* matrix.rs:124: 1 = Some, 0 = None (|det| < EPSILON) */
+
+/* ---- src/material.rs:11-21 + src/pattern.rs ---- */
+typedef struct rth_material {
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    int32_t pattern_kind; /* RT_PAT_* or -1 = None */
+    int32_t _pad;
+    double pattern_a[3], pattern_b[3];
+    double pattern_transform[16];
+} rth_material;
+void rth_material_default(rth_material* out); /* impl Default for Material, material.rs:23-37 */
+
+/* ---- shapes (src/shape.rs and the nine shape modules) ---- */
+int rth_shape_new(int kind);      /* RT_SPHERE, RT_PLANE, RT_CUBE, RT_CYLINDER, RT_CONE, RT_GROUP: X::new() */
+int rth_glass_sphere(void);       /* Sphere::glass_sphere, sphere.rs:69 */
+int rth_triangle_new(const double* p1, const double* p2, const double* p3); /* triangle.rs:38 */
+int rth_smooth_triangle_new(const double* p1, const double* p2, const double* p3, const double* n1,
+                            const double* n2, const double* n3);            /* smooth_triangle.rs:42 */
+int rth_csg_new(const char* operation, int left, int right); /* CSG::new, csg.rs:33: sets both parents */
+int rth_hexagon(void);                                       /* lib.rs:116 */
+int rth_shape_clone(int shape);
+void rth_shape_free(int shape);
+int rth_shape_kind(int shape);
+int rth_shape_id(int shape);                                 /* get_id */
+int rth_shape_parent(int shape);                             /* get_parent: id or 0 for None */
+int rth_shape_set_transform(int shape, const double* m16);   /* shape.rs:140 */
+int rth_shape_set_material(int shape, const rth_material* m);/* shape.rs:186 */
+int rth_shape_get_material(int shape, rth_material* out);    /* shape.rs:163: ROOT ancestor's material */
+int rth_shape_set_casts_shadow(int shape, int v);            /* shape.rs:224 */
+int rth_shape_set_minimum(int shape, double v);              /* shape.rs:255 (error unless cylinder/cone) */
+int rth_shape_set_maximum(int shape, double v);
+int rth_shape_set_closed(int shape, int v);
+int rth_group_add_child(int group, int child);               /* group.rs:45: child gets its parent set, a CLONE is stored */
+int rth_shape_child_count(int shape);                        /* get_shapes().len() */
+int rth_shape_child(int shape, int index);                   /* new handle holding a clone of get_shapes()[index] */
+int rth_shape_divide(int shape, int threshold);              /* group.rs:134 */
+int rth_shape_bounds_of(int shape, double* out6);            /* bounds_of: min xyz, max xyz */
+int rth_shape_parent_space_bounds_of(int shape, double* out6);
+int rth_shape_includes(int shape, int other);                /* shape.rs:422 */
+int rth_shape_eq(int a, int b);                              /* PartialEq */
+/* get_points / get_normal_vectors and the derived fields: out [9][3] = point1, point2, point3, edge_vector1,
+ * edge_vector2, normal_vector, normal_vector1, normal_vector2, normal_vector3 (last three 0 for flat triangles) */
+int rth_triangle_data(int shape, double* out27);
+
+/* ---- src/obj_file.rs ---- */
+/* parse_obj_file + obj_to_group.  counts_out (nullable) = {lines_ignored, vertices.len(), normals.len(),
+ * groups.len(), total triangles}.  Returns the handle of the main group. */
+int rth_obj_to_group(const char* text, int64_t len, int32_t* counts_out);
+
+/* ---- src/world.rs ---- */
+/* Builds a World from CLONES of the given shapes (world.objects order) and lights (world.lights order). */
+int rth_world_create(const int* shapes, int n_shapes, const double* light_positions, const double* light_intensities,
+                     int n_lights);
+void rth_world_free(int world);
+/* Flattened tables for the hot path; owned by the world handle, valid until rth_world_free. */
+const rt_scene_desc* rth_world_flatten(int world);
+/* Device copy (rt_scene_create on first use); owned by the world handle. */
+rt_scene* rth_world_scene(int world, int device);
+
+/* ---- src/camera.rs:21-35: Camera::new + transform -> descriptor for rt_render ---- */
+int rth_camera_desc(int hsize, int vsize, double field_of_view, const double* transform16, rt_camera_desc* out);
+
+/* ---- src/canvas.rs:33-98: canvas_to_ppm over an f64 RGB frame.  Returns the byte length (may exceed cap). ---- */
+int64_t rth_canvas_to_ppm(const double* rgb, int width, int height, char* out, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,848 @@
+/*
+ * rt_oracle.c — TEST INFRASTRUCTURE ONLY.  CPU restatement, in plain C, of the reference crate's per-pixel
+ * render path (ashcolecarr/Ray-Tracer: Camera::render -> World::color_at) operating on the same flattened
+ * tables (include/rt_abi.h) the GPU path consumes.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library.  The
+ * product (ray-tracer_amd/) never links, imports or calls it.
+ *
+ * How it is pinned: the reference is Rust and there is no Rust toolchain in the build image (no rustc/cargo,
+ * lazy_static not vendored), so the reference itself cannot be run here.  The restatement is pinned instead by
+ * the reference's own unit-test vectors (tests/golden/reference_kats.json transcribes them; tests/test_oracle_kats.py
+ * replays them, tolerance 1e-5 = the reference's near_eq).  Behaviours no reference test covers (last row/column
+ * skipped, xs[0] u/v for smooth triangles, n1/n2 double match, nearest-hit-only shadows, infinite boxes of triangle
+ * groups, stable-sort tie order) follow the cited source text literally.
+ *
+ * Style: deliberately literal.  Intersection lists are materialised and stable-sorted at every level exactly where
+ * the reference sorts them, tuples carry w, matrix*tuple starts from 0.0 and sums left to right, there is no
+ * acceleration structure and no early exit.  Build with -O2 -ffp-contract=off (Rust never contracts).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt_abi.h"
+
+#define EPSILON 0.00001 /* src/lib.rs:42 */
+
+typedef struct { double x, y, z, w; } tup;
+typedef struct { double r, g, b; } col;
+typedef struct { tup origin, direction; } ray_t;
+typedef struct { double t; int node; int has_uv; double u, v; } isect; /* src/intersection.rs:8-13 */
+typedef struct { isect* v; int n, cap; } ilist;
+
+typedef struct orc_stats {
+    int64_t rays_primary, rays_reflect, rays_refract, rays_shadow, shaded_nodes;
+} orc_stats;
+
+static orc_stats g_stats;
+static unsigned g_flags; /* RT_FLAG_* raised while evaluating the current top-level ray */
+
+static int near_eq(double a, double b) { return fabs(a - b) < EPSILON; } /* src/lib.rs:56-62 */
+
+/* ---------------------------------------------------------------- tuple.rs */
+static tup T(double x, double y, double z, double w) { tup t = {x, y, z, w}; return t; }
+static tup point(double x, double y, double z) { return T(x, y, z, 1.); }
+static tup vector(double x, double y, double z) { return T(x, y, z, 0.); }
+static tup tadd(tup a, tup b) { return T(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static tup tsub(tup a, tup b) { return T(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+static tup tneg(tup a) { return T(-a.x, -a.y, -a.z, -a.w); }
+static tup tmul(tup a, double s) { return T(a.x * s, a.y * s, a.z * s, a.w * s); }
+static double dot(tup a, tup b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z) + (a.w * b.w); } /* :45-47 */
+static double magnitude(tup a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w); }   /* :32-34 */
+static tup normalize(tup a) { /* :36-43: four divisions by the magnitude */
+    double m = magnitude(a);
+    return T(a.x / m, a.y / m, a.z / m, a.w / m);
+}
+static tup cross(tup a, tup b) { /* :49-52 */
+    return vector((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+static tup reflect(tup v, tup n) { return tsub(v, tmul(tmul(n, 2.), dot(v, n))); } /* :54-56 */
+
+/* ---------------------------------------------------------------- color.rs */
+static col C(double r, double g, double b) { col c = {r, g, b}; return c; }
+static col cadd(col a, col b) { return C(a.r + b.r, a.g + b.g, a.b + b.b); }
+static col csub(col a, col b) { return C(a.r - b.r, a.g - b.g, a.b - b.b); }
+static col cscale(col a, double s) { return C(a.r * s, a.g * s, a.b * s); }
+static col chad(col a, col b) { return C(a.r * b.r, a.g * b.g, a.b * b.b); }
+static const col BLACK = {0., 0., 0.};
+
+/* ---------------------------------------------------------------- matrix.rs:171-200 */
+static tup mat_tuple(const double* m, tup t) {
+    double o[4];
+    for (int r = 0; r < 4; ++r) {
+        double p = 0.0;
+        p += m[r * 4 + 0] * t.x;
+        p += m[r * 4 + 1] * t.y;
+        p += m[r * 4 + 2] * t.z;
+        p += m[r * 4 + 3] * t.w;
+        o[r] = p;
+    }
+    return T(o[0], o[1], o[2], o[3]);
+}
+
+/* ---------------------------------------------------------------- ray.rs */
+static tup position(ray_t r, double t) { return tadd(r.origin, tmul(r.direction, t)); } /* :21-23 */
+static ray_t ray_transform(ray_t r, const double* m) {                                   /* :25-30 */
+    ray_t o;
+    o.origin = mat_tuple(m, r.origin);
+    o.direction = mat_tuple(m, r.direction);
+    return o;
+}
+
+/* ---------------------------------------------------------------- lists */
+static void il_init(ilist* l) { l->v = NULL; l->n = 0; l->cap = 0; }
+static void il_free(ilist* l) { free(l->v); l->v = NULL; l->n = l->cap = 0; }
+static void il_push(ilist* l, isect i) {
+    if (l->n == l->cap) {
+        l->cap = l->cap ? l->cap * 2 : 8;
+        l->v = (isect*)realloc(l->v, (size_t)l->cap * sizeof(isect));
+    }
+    l->v[l->n++] = i;
+}
+static void il_append(ilist* dst, const ilist* src) {
+    for (int i = 0; i < src->n; ++i) il_push(dst, src->v[i]);
+}
+static void push_t(ilist* l, double t, int node) { isect i = {t, node, 0, 0., 0.}; il_push(l, i); }
+/* Vec::sort_by(|a,b| a.t.partial_cmp(&b.t).unwrap()): stable; a NaN t panics the reference -> flag. */
+static void il_sort(ilist* l) {
+    for (int i = 0; i < l->n; ++i)
+        if (isnan(l->v[i].t)) g_flags |= RT_FLAG_NAN_T;
+    for (int i = 1; i < l->n; ++i) { /* insertion sort is stable */
+        isect k = l->v[i];
+        int j = i - 1;
+        while (j >= 0 && l->v[j].t > k.t) { l->v[j + 1] = l->v[j]; --j; }
+        l->v[j + 1] = k;
+    }
+}
+
+/* ---------------------------------------------------------------- primitives */
+static const double* xf_inv(const rt_scene_desc* d, int x) { return d->xform_inverse + (size_t)x * 16; }
+static const double* xf_inv_t(const rt_scene_desc* d, int x) { return d->xform_inverse_transpose + (size_t)x * 16; }
+static tup ld3p(const double* a, int i) { return point(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+static tup ld3v(const double* a, int i) { return vector(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+
+static void sphere_intersect(int node, ray_t ray, ilist* out) { /* src/sphere.rs:43-63 */
+    tup sphere_to_ray = tsub(ray.origin, point(0., 0., 0.));
+    double a = dot(ray.direction, ray.direction);
+    double b = 2. * dot(ray.direction, sphere_to_ray);
+    double c = dot(sphere_to_ray, sphere_to_ray) - 1.;
+    double discriminant = b * b - 4. * a * c;
+    if (discriminant < 0.) return;
+    double t1 = (-b - sqrt(discriminant)) / (2. * a);
+    double t2 = (-b + sqrt(discriminant)) / (2. * a);
+    push_t(out, t1, node);
+    push_t(out, t2, node);
+}
+
+static void plane_intersect(int node, ray_t ray, ilist* out) { /* src/plane.rs:44-51 */
+    if (fabs(ray.direction.y) < EPSILON) return;
+    push_t(out, -ray.origin.y / ray.direction.y, node);
+}
+
+/* src/cube.rs:63-79 and src/bound.rs:100-116 (same code with the box limits as parameters) */
+static void check_axis(double origin, double direction, double minimum, double maximum, double* tmin_o, double* tmax_o) {
+    double tmin_numerator = minimum - origin;
+    double tmax_numerator = maximum - origin;
+    double tmin, tmax;
+    if (fabs(direction) >= EPSILON) {
+        tmin = tmin_numerator / direction;
+        tmax = tmax_numerator / direction;
+    } else {
+        tmin = tmin_numerator * INFINITY;
+        tmax = tmax_numerator * INFINITY;
+    }
+    if (tmin > tmax) { *tmin_o = tmax; *tmax_o = tmin; } else { *tmin_o = tmin; *tmax_o = tmax; }
+}
+/* fold(0./0., f64::max) — f64::max/min ignore a NaN operand, as C fmax/fmin do */
+static double max3nan(double a, double b, double c) { return fmax(fmax(fmax(NAN, a), b), c); }
+static double min3nan(double a, double b, double c) { return fmin(fmin(fmin(NAN, a), b), c); }
+
+static void cube_intersect(int node, ray_t ray, ilist* out) { /* src/cube.rs:45-61 */
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(ray.origin.x, ray.direction.x, -1., 1., &xtmin, &xtmax);
+    check_axis(ray.origin.y, ray.direction.y, -1., 1., &ytmin, &ytmax);
+    check_axis(ray.origin.z, ray.direction.z, -1., 1., &ztmin, &ztmax);
+    double tmin = max3nan(xtmin, ytmin, ztmin);
+    double tmax = min3nan(xtmax, ytmax, ztmax);
+    if (tmin > tmax) return;
+    push_t(out, tmin, node);
+    push_t(out, tmax, node);
+}
+
+static int bound_intersects(const double* box, ray_t ray) { /* src/bound.rs:85-98 */
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(ray.origin.x, ray.direction.x, box[0], box[3], &xtmin, &xtmax);
+    check_axis(ray.origin.y, ray.direction.y, box[1], box[4], &ytmin, &ytmax);
+    check_axis(ray.origin.z, ray.direction.z, box[2], box[5], &ztmin, &ztmax);
+    double tmin = max3nan(xtmin, ytmin, ztmin);
+    double tmax = min3nan(xtmax, ytmax, ztmax);
+    if (tmin > tmax) return 0;
+    return 1;
+}
+
+static int cyl_check_cap(ray_t ray, double t) { /* src/cylinder.rs:104-111 */
+    double x = ray.origin.x + t * ray.direction.x;
+    double z = ray.origin.z + t * ray.direction.z;
+    double result = x * x + z * z;
+    return result < 1. || near_eq(result, 1.);
+}
+static void cylinder_intersect(const rt_scene_desc* d, int node, ray_t ray, ilist* out) { /* src/cylinder.rs:53-102 */
+    int p = d->node_param[node];
+    double minimum = d->conic_minimum[p], maximum = d->conic_maximum[p];
+    int closed = d->conic_closed[p];
+    int n0 = out->n;
+    double a = ray.direction.x * ray.direction.x + ray.direction.z * ray.direction.z;
+    if (!near_eq(a, 0.)) {
+        double b = 2. * ray.origin.x * ray.direction.x + 2. * ray.origin.z * ray.direction.z;
+        double c = ray.origin.x * ray.origin.x + ray.origin.z * ray.origin.z - 1.;
+        double disc = b * b - 4. * a * c;
+        if (disc < 0.) { out->n = n0; return; } /* `return vec![]` — caps are skipped too */
+        double t0 = (-b - sqrt(disc)) / (2. * a);
+        double t1 = (-b + sqrt(disc)) / (2. * a);
+        if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+        double y0 = ray.origin.y + t0 * ray.direction.y;
+        if (minimum < y0 && y0 < maximum) push_t(out, t0, node);
+        double y1 = ray.origin.y + t1 * ray.direction.y;
+        if (minimum < y1 && y1 < maximum) push_t(out, t1, node);
+    }
+    if (!closed || near_eq(ray.direction.y, 0.)) return; /* intersect_caps :88-102 */
+    double t_lower = (minimum - ray.origin.y) / ray.direction.y;
+    if (cyl_check_cap(ray, t_lower)) push_t(out, t_lower, node);
+    double t_upper = (maximum - ray.origin.y) / ray.direction.y;
+    if (cyl_check_cap(ray, t_upper)) push_t(out, t_upper, node);
+}
+
+static int cone_check_cap(ray_t ray, double t, double y) { /* src/cone.rs:110-117 */
+    double x = ray.origin.x + t * ray.direction.x;
+    double z = ray.origin.z + t * ray.direction.z;
+    double result = x * x + z * z;
+    return result < y * y || near_eq(result, y * y);
+}
+static void cone_intersect(const rt_scene_desc* d, int node, ray_t ray, ilist* out) { /* src/cone.rs:53-108 */
+    int p = d->node_param[node];
+    double minimum = d->conic_minimum[p], maximum = d->conic_maximum[p];
+    int closed = d->conic_closed[p];
+    tup o = ray.origin, dir = ray.direction;
+    double a = dir.x * dir.x - dir.y * dir.y + dir.z * dir.z;
+    double b = 2. * o.x * dir.x - 2. * o.y * dir.y + 2. * o.z * dir.z;
+    double c = o.x * o.x - o.y * o.y + o.z * o.z;
+    if (near_eq(a, 0.) && !near_eq(b, 0.)) {
+        double t = -c / (2. * b);
+        push_t(out, t, node);
+    }
+    if (!near_eq(a, 0.)) {
+        double disc = b * b - 4. * a * c;
+        if (disc > 0. || near_eq(disc, 0.)) {
+            double t0 = (-b - sqrt(disc)) / (2. * a);
+            double t1 = (-b + sqrt(disc)) / (2. * a);
+            if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+            double y0 = o.y + t0 * dir.y;
+            if (minimum < y0 && y0 < maximum) push_t(out, t0, node);
+            double y1 = o.y + t1 * dir.y;
+            if (minimum < y1 && y1 < maximum) push_t(out, t1, node);
+        }
+    }
+    if (!closed || near_eq(dir.y, 0.)) return; /* intersect_caps :94-108 */
+    double t_lower = (minimum - o.y) / dir.y;
+    if (cone_check_cap(ray, t_lower, minimum)) push_t(out, t_lower, node);
+    double t_upper = (maximum - o.y) / dir.y;
+    if (cone_check_cap(ray, t_upper, maximum)) push_t(out, t_upper, node);
+}
+
+/* src/triangle.rs:62-87 and src/smooth_triangle.rs:71-96 (identical arithmetic; the smooth one keeps u,v) */
+static void triangle_intersect(const rt_scene_desc* d, int node, ray_t ray, ilist* out) {
+    int p = d->node_param[node];
+    tup point1 = ld3p(d->tri_p1, p), edge_vector1 = ld3v(d->tri_e1, p), edge_vector2 = ld3v(d->tri_e2, p);
+    tup dir_cross_e2 = cross(ray.direction, edge_vector2);
+    double determinant = dot(edge_vector1, dir_cross_e2);
+    if (fabs(determinant) < EPSILON) return;
+    double f = 1.0 / determinant;
+    tup p1_to_origin = tsub(ray.origin, point1);
+    double u = f * dot(p1_to_origin, dir_cross_e2);
+    if (u < 0. || u > 1.) return;
+    tup origin_cross_e1 = cross(p1_to_origin, edge_vector1);
+    double v = f * dot(ray.direction, origin_cross_e1);
+    if (v < 0. || (u + v) > 1.) return;
+    double t = f * dot(edge_vector2, origin_cross_e1);
+    isect i = {t, node, d->node_kind[node] == RT_SMOOTH_TRIANGLE, u, v};
+    il_push(out, i);
+}
+
+/* ---------------------------------------------------------------- shape.rs:74-90, group.rs:52-65, csg.rs:66-126 */
+static void intersect_node(const rt_scene_desc* d, int node, ray_t ray, ilist* out);
+
+static int node_in_subtree(const rt_scene_desc* d, int root, int node) { /* Shape::includes, src/shape.rs:422-435 */
+    /* membership is by object id in the reference; ids are unique per Shape value unless the same shape was
+     * cloned into both operands, so compare ids over the subtree's leaves */
+    int id = d->node_object_id[node];
+    for (int i = root; i < d->node_subtree_end[root]; ++i) {
+        int k = d->node_kind[i];
+        if (k != RT_GROUP && k != RT_CSG && d->node_object_id[i] == id) return 1;
+    }
+    return 0;
+}
+
+static int intersection_allowed(int op, int left_hit, int inside_left_hit, int inside_right_hit) { /* csg.rs:95-104 */
+    switch (op) {
+        case RT_CSG_UNION: return (left_hit && !inside_right_hit) || (!left_hit && !inside_left_hit);
+        case RT_CSG_INTERSECTION: return (left_hit && inside_right_hit) || (!left_hit && inside_left_hit);
+        case RT_CSG_DIFFERENCE: return (left_hit && !inside_right_hit) || (!left_hit && inside_left_hit);
+        default: return 0;
+    }
+}
+
+static void intersect_node(const rt_scene_desc* d, int node, ray_t ray, ilist* out) {
+    ray_t local_ray = ray_transform(ray, xf_inv(d, d->node_xform[node])); /* src/shape.rs:75-76 */
+    switch (d->node_kind[node]) {
+        case RT_SPHERE: sphere_intersect(node, local_ray, out); break;
+        case RT_PLANE: plane_intersect(node, local_ray, out); break;
+        case RT_CUBE: cube_intersect(node, local_ray, out); break;
+        case RT_CYLINDER: cylinder_intersect(d, node, local_ray, out); break;
+        case RT_CONE: cone_intersect(d, node, local_ray, out); break;
+        case RT_TRIANGLE:
+        case RT_SMOOTH_TRIANGLE: triangle_intersect(d, node, local_ray, out); break;
+        case RT_GROUP: { /* src/group.rs:52-65 */
+            if (bound_intersects(d->group_box + (size_t)d->node_param[node] * 6, local_ray)) {
+                ilist xs;
+                il_init(&xs);
+                for (int c = node + 1; c < d->node_subtree_end[node]; c = d->node_subtree_end[c])
+                    intersect_node(d, c, local_ray, &xs);
+                il_sort(&xs);
+                il_append(out, &xs);
+                il_free(&xs);
+            }
+            break;
+        }
+        case RT_CSG: { /* src/csg.rs:66-74 */
+            int left = node + 1, right = d->node_subtree_end[left];
+            ilist xs;
+            il_init(&xs);
+            intersect_node(d, left, local_ray, &xs);
+            intersect_node(d, right, local_ray, &xs);
+            il_sort(&xs);
+            int inside_left_hit = 0, inside_right_hit = 0; /* filter_intersections :106-126 */
+            int op = d->csg_op[d->node_param[node]];
+            for (int i = 0; i < xs.n; ++i) {
+                int left_hit = node_in_subtree(d, left, xs.v[i].node);
+                if (intersection_allowed(op, left_hit, inside_left_hit, inside_right_hit)) il_push(out, xs.v[i]);
+                if (left_hit) inside_left_hit = !inside_left_hit; else inside_right_hit = !inside_right_hit;
+            }
+            il_free(&xs);
+            break;
+        }
+        default: break;
+    }
+}
+
+static void intersect_world(const rt_scene_desc* d, ray_t ray, ilist* out) { /* src/world.rs:46-55 */
+    for (int n = 0; n < d->n_nodes; n = d->node_subtree_end[n]) intersect_node(d, n, ray, out);
+    il_sort(out);
+}
+
+static int hit_index(const ilist* xs) { /* Intersection::hit, src/intersection.rs:30-36 */
+    for (int i = 0; i < xs->n; ++i)
+        if (xs->v[i].t > 0.) return i;
+    return -1;
+}
+
+/* ---------------------------------------------------------------- normals: shape.rs:92-108,394-420 */
+static tup ancestor_world_to_object(const rt_scene_desc* d, int anc, tup p) {
+    if (d->ancestor_parent[anc] >= 0) p = ancestor_world_to_object(d, d->ancestor_parent[anc], p);
+    return mat_tuple(xf_inv(d, d->ancestor_xform[anc]), p);
+}
+static tup world_to_object(const rt_scene_desc* d, int node, tup p) { /* :394-404 */
+    if (d->node_ancestor[node] >= 0) p = ancestor_world_to_object(d, d->node_ancestor[node], p);
+    return mat_tuple(xf_inv(d, d->node_xform[node]), p);
+}
+static tup normal_step(const rt_scene_desc* d, int xform, tup n) { /* :407-409 */
+    tup nn = mat_tuple(xf_inv_t(d, xform), n);
+    nn.w = 0.;
+    return normalize(nn);
+}
+static tup normal_to_world(const rt_scene_desc* d, int node, tup n) { /* :406-420 */
+    n = normal_step(d, d->node_xform[node], n);
+    for (int a = d->node_ancestor[node]; a >= 0; a = d->ancestor_parent[a]) n = normal_step(d, d->ancestor_xform[a], n);
+    return n;
+}
+
+static tup local_normal_at(const rt_scene_desc* d, int node, tup p, const isect* first, const isect* hit) {
+    int prm = d->node_param[node];
+    switch (d->node_kind[node]) {
+        case RT_SPHERE: return tsub(p, point(0., 0., 0.)); /* src/sphere.rs:65-67 */
+        case RT_PLANE: return vector(0., 1., 0.);           /* src/plane.rs:53-56 */
+        case RT_CUBE: {                                     /* src/cube.rs:81-92 */
+            double maxc = max3nan(fabs(p.x), fabs(p.y), fabs(p.z));
+            if (near_eq(maxc, fabs(p.x))) return vector(p.x, 0., 0.);
+            else if (near_eq(maxc, fabs(p.y))) return vector(0., p.y, 0.);
+            else return vector(0., 0., p.z);
+        }
+        case RT_CYLINDER: { /* src/cylinder.rs:113-127 */
+            double minimum = d->conic_minimum[prm], maximum = d->conic_maximum[prm];
+            double distance = p.x * p.x + p.z * p.z;
+            if (distance < 1. && (p.y > maximum - EPSILON || near_eq(p.y, maximum - EPSILON))) return vector(0., 1., 0.);
+            else if (distance < 1. && (p.y < minimum + EPSILON || near_eq(p.y, minimum + EPSILON))) return vector(0., -1., 0.);
+            else return vector(p.x, 0., p.z);
+        }
+        case RT_CONE: { /* src/cone.rs:119-135 */
+            double minimum = d->conic_minimum[prm], maximum = d->conic_maximum[prm];
+            double distance = p.x * p.x + p.z * p.z;
+            if (distance < maximum * maximum && (p.y > maximum - EPSILON || near_eq(p.y, maximum - EPSILON))) return vector(0., 1., 0.);
+            else if (distance < minimum * minimum && (p.y < minimum + EPSILON || near_eq(p.y, minimum + EPSILON))) return vector(0., -1., 0.);
+            else {
+                double y = sqrt(distance);
+                return vector(p.x, p.y > 0. ? -y : y, p.z);
+            }
+        }
+        case RT_TRIANGLE: return ld3v(d->tri_normal, prm); /* src/triangle.rs:89-91 */
+        case RT_SMOOTH_TRIANGLE: {                          /* src/smooth_triangle.rs:98-104 */
+            const isect* src = first; /* the u,v of intersections[0] (src/intersection.rs:40) */
+            if (!first->has_uv) {     /* `hit.u.unwrap()` panics in the reference */
+                g_flags |= RT_FLAG_REF_PANIC_UV;
+                src = hit;
+            }
+            int s = d->tri_smooth[prm];
+            tup n1 = ld3v(d->smooth_n1, s), n2 = ld3v(d->smooth_n2, s), n3 = ld3v(d->smooth_n3, s);
+            double hit_u = src->u, hit_v = src->v;
+            return tadd(tadd(tmul(n2, hit_u), tmul(n3, hit_v)), tmul(n1, (1. - hit_u - hit_v)));
+        }
+        default: return vector(0., 0., 0.);
+    }
+}
+
+static tup normal_at(const rt_scene_desc* d, int node, tup world_point, const isect* first, const isect* hit) {
+    tup local_point = world_to_object(d, node, world_point);
+    tup local_normal = local_normal_at(d, node, local_point, first, hit);
+    return normal_to_world(d, node, local_normal);
+}
+
+/* ---------------------------------------------------------------- computations.rs + intersection.rs:38-95 */
+typedef struct {
+    double t; int node;
+    tup point, eye_vector, normal_vector; int inside;
+    tup over_point, reflect_vector; double n1, n2; tup under_point;
+} comps_t;
+
+static int shape_eq(const rt_scene_desc* d, int a, int b) {
+    return d->node_eq_class[a] >= 0 && d->node_eq_class[a] == d->node_eq_class[b];
+}
+static double mat_param(const rt_scene_desc* d, int node, int col_) {
+    return d->material_params[(size_t)d->node_material[node] * RT_MAT_STRIDE + col_];
+}
+
+static comps_t prepare_computations(const rt_scene_desc* d, const isect* self, ray_t ray, const ilist* xs) {
+    comps_t c;
+    c.t = self->t;
+    c.node = self->node;
+    c.point = position(ray, self->t);
+    c.normal_vector = normal_at(d, self->node, c.point, &xs->v[0], self);
+    c.eye_vector = tneg(ray.direction);
+    if (dot(c.normal_vector, c.eye_vector) < 0.) {
+        c.normal_vector = tneg(c.normal_vector);
+        c.inside = 1;
+    } else {
+        c.inside = 0;
+    }
+    c.over_point = tadd(c.point, tmul(c.normal_vector, EPSILON));
+    c.under_point = tsub(c.point, tmul(c.normal_vector, EPSILON));
+    c.reflect_vector = reflect(ray.direction, c.normal_vector);
+
+    double n1 = 0., n2 = 0.;
+    int* containers = (int*)malloc(sizeof(int) * (size_t)(xs->n + 1));
+    int nc = 0;
+    for (int i = 0; i < xs->n; ++i) { /* all of them, no break: :57-80 */
+        const isect* x = &xs->v[i];
+        int is_self = near_eq(x->t, self->t) && shape_eq(d, x->node, self->node); /* Intersection::eq :15-19 */
+        if (is_self) n1 = nc == 0 ? 1. : mat_param(d, containers[nc - 1], RT_MAT_REFRACTIVE_INDEX);
+        int found = -1;
+        for (int k = 0; k < nc; ++k)
+            if (shape_eq(d, containers[k], x->node)) { found = k; break; }
+        if (found >= 0) {
+            for (int k = found; k + 1 < nc; ++k) containers[k] = containers[k + 1];
+            --nc;
+        } else {
+            containers[nc++] = x->node;
+        }
+        if (is_self) n2 = nc == 0 ? 1. : mat_param(d, containers[nc - 1], RT_MAT_REFRACTIVE_INDEX);
+    }
+    free(containers);
+    c.n1 = n1;
+    c.n2 = n2;
+    return c;
+}
+
+static double schlick(const comps_t* c) { /* src/intersection.rs:97-115 */
+    double cosv = dot(c->eye_vector, c->normal_vector);
+    if (c->n1 > c->n2) {
+        double n = c->n1 / c->n2;
+        double sin2_t = (n * n) * (1. - cosv * cosv);
+        if (sin2_t > 1.) return 1.;
+        double cos_t = sqrt(1. - sin2_t);
+        cosv = cos_t;
+    }
+    double q = (c->n1 - c->n2) / (c->n1 + c->n2);
+    double r0 = q * q;
+    double x = 1. - cosv;
+    return r0 + (1. - r0) * (x * ((x * x) * (x * x))); /* powi(5) */
+}
+
+/* ---------------------------------------------------------------- pattern.rs */
+static int as_i32(double x) { /* Rust `as i32`: saturating, NaN -> 0 */
+    if (isnan(x)) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return (-2147483647 - 1);
+    return (int)x;
+}
+static col pattern_at_shape(const rt_scene_desc* d, int pat, int node, tup world_point) { /* :23-35 */
+    tup object_point = world_to_object(d, node, world_point);
+    tup p = mat_tuple(d->pattern_inverse + (size_t)pat * 16, object_point);
+    col a = C(d->pattern_a[3 * pat], d->pattern_a[3 * pat + 1], d->pattern_a[3 * pat + 2]);
+    col b = C(d->pattern_b[3 * pat], d->pattern_b[3 * pat + 1], d->pattern_b[3 * pat + 2]);
+    switch (d->pattern_kind[pat]) {
+        case RT_PAT_STRIPED: return as_i32(floor(p.x)) % 2 == 0 ? a : b; /* :72-78 */
+        case RT_PAT_GRADIENT: {                                           /* :93-98 */
+            col distance = csub(b, a);
+            double fraction = p.x - floor(p.x);
+            return cadd(a, cscale(distance, fraction));
+        }
+        case RT_PAT_RING: return as_i32(floor(sqrt(p.x * p.x + p.z * p.z))) % 2 == 0 ? a : b; /* :113-119 */
+        case RT_PAT_CHECKERED: return as_i32(floor(p.x) + floor(p.y) + floor(p.z)) % 2 == 0 ? a : b; /* :134-140 */
+        case RT_PAT_RING_GRADIENT: { /* :155-161 */
+            col distance = csub(b, a);
+            double cc = sqrt(p.x * p.x + p.z * p.z);
+            double fraction = cc - floor(cc);
+            return cadd(a, cscale(distance, fraction));
+        }
+        default: return C(p.x, p.y, p.z); /* TestPattern :175-177 */
+    }
+}
+
+/* ---------------------------------------------------------------- material.rs:97-129 */
+static col lighting(const rt_scene_desc* d, int node, int light, tup pt, tup eye_vector, tup normal_vector, int in_shadow) {
+    const double* m = d->material_params + (size_t)d->node_material[node] * RT_MAT_STRIDE;
+    int pat = d->material_pattern[d->node_material[node]];
+    col real_color = pat >= 0 ? pattern_at_shape(d, pat, node, pt) : C(m[RT_MAT_R], m[RT_MAT_G], m[RT_MAT_B]);
+    col intensity = C(d->light_intensity[3 * light], d->light_intensity[3 * light + 1], d->light_intensity[3 * light + 2]);
+    tup light_position = ld3p(d->light_position, light);
+    col effective_color = chad(real_color, intensity);
+    tup light_vector = normalize(tsub(light_position, pt));
+    col ambient = cscale(effective_color, m[RT_MAT_AMBIENT]);
+    double light_dot_normal = dot(light_vector, normal_vector);
+    col diffuse, specular;
+    if (light_dot_normal < 0.) {
+        diffuse = BLACK;
+        specular = BLACK;
+    } else {
+        diffuse = cscale(cscale(effective_color, m[RT_MAT_DIFFUSE]), light_dot_normal);
+        tup reflect_vector = reflect(tneg(light_vector), normal_vector);
+        double reflect_dot_eye = dot(reflect_vector, eye_vector);
+        if (near_eq(0., reflect_dot_eye) || reflect_dot_eye < 0.) {
+            specular = BLACK;
+        } else {
+            double factor = pow(reflect_dot_eye, m[RT_MAT_SHININESS]);
+            specular = cscale(cscale(intensity, m[RT_MAT_SPECULAR]), factor);
+        }
+    }
+    if (in_shadow) return ambient;
+    return cadd(cadd(ambient, diffuse), specular);
+}
+
+/* ---------------------------------------------------------------- world.rs */
+static col color_at(const rt_scene_desc* d, ray_t ray, int remaining, int* hit_id_out);
+
+static int is_shadowed_one(const rt_scene_desc* d, tup pt, int light) { /* :92-107 */
+    tup v = tsub(ld3p(d->light_position, light), pt);
+    double distance = magnitude(v);
+    tup direction = normalize(v);
+    ray_t r = {pt, direction};
+    ilist xs;
+    il_init(&xs);
+    g_stats.rays_shadow++;
+    intersect_world(d, r, &xs);
+    int h = hit_index(&xs);
+    int res = 0;
+    if (h >= 0) res = xs.v[h].t < distance && d->node_casts_shadow[xs.v[h].node];
+    il_free(&xs);
+    return res;
+}
+
+static col reflected_color(const rt_scene_desc* d, const comps_t* c, int remaining) { /* :109-118 */
+    double reflective = mat_param(d, c->node, RT_MAT_REFLECTIVE);
+    if (near_eq(reflective, 0.) || remaining <= 0) return BLACK;
+    ray_t r = {c->over_point, c->reflect_vector};
+    g_stats.rays_reflect++;
+    col color = color_at(d, r, remaining - 1, NULL);
+    return cscale(color, reflective);
+}
+
+static col refracted_color(const rt_scene_desc* d, const comps_t* c, int remaining) { /* :120-137 */
+    double transparency = mat_param(d, c->node, RT_MAT_TRANSPARENCY);
+    if (near_eq(transparency, 0.) || remaining <= 0) return BLACK;
+    double n_ratio = c->n1 / c->n2;
+    double cos_i = dot(c->eye_vector, c->normal_vector);
+    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+    if (sin2_t > 1.) return BLACK;
+    double cos_t = sqrt(1. - sin2_t);
+    tup direction = tsub(tmul(c->normal_vector, (n_ratio * cos_i - cos_t)), tmul(c->eye_vector, n_ratio));
+    ray_t r = {c->under_point, direction};
+    g_stats.rays_refract++;
+    return cscale(color_at(d, r, remaining - 1, NULL), transparency);
+}
+
+static col shade_hit(const rt_scene_desc* d, const comps_t* c, int remaining) { /* :57-79 */
+    col surface = BLACK;
+    int* shadowed = (int*)malloc(sizeof(int) * (size_t)(d->n_lights + 1));
+    for (int l = 0; l < d->n_lights; ++l) shadowed[l] = is_shadowed_one(d, c->over_point, l);
+    for (int l = 0; l < d->n_lights; ++l)
+        surface = cadd(surface, lighting(d, c->node, l, c->over_point, c->eye_vector, c->normal_vector, shadowed[l]));
+    free(shadowed);
+    col reflected = reflected_color(d, c, remaining);
+    col refracted = refracted_color(d, c, remaining);
+    double reflective = mat_param(d, c->node, RT_MAT_REFLECTIVE), transparency = mat_param(d, c->node, RT_MAT_TRANSPARENCY);
+    if (reflective > 0. && transparency > 0.) {
+        double reflectance = schlick(c);
+        return cadd(cadd(surface, cscale(reflected, reflectance)), cscale(refracted, (1. - reflectance)));
+    }
+    return cadd(cadd(surface, reflected), refracted);
+}
+
+static col color_at(const rt_scene_desc* d, ray_t ray, int remaining, int* hit_id_out) { /* :81-90 */
+    ilist xs;
+    il_init(&xs);
+    intersect_world(d, ray, &xs);
+    int h = hit_index(&xs);
+    col out = BLACK;
+    if (hit_id_out) *hit_id_out = h >= 0 ? d->node_object_id[xs.v[h].node] : 0;
+    if (h >= 0) {
+        g_stats.shaded_nodes++;
+        comps_t c = prepare_computations(d, &xs.v[h], ray, &xs);
+        out = shade_hit(d, &c, remaining);
+    }
+    il_free(&xs);
+    return out;
+}
+
+/* ---------------------------------------------------------------- camera.rs:37-60 */
+static ray_t ray_for_pixel(const rt_camera_desc* cam, unsigned px, unsigned py) {
+    double x_offset = ((double)px + 0.5) * cam->pixel_size;
+    double y_offset = ((double)py + 0.5) * cam->pixel_size;
+    double world_x = cam->half_width - x_offset;
+    double world_y = cam->half_height - y_offset;
+    ray_t r;
+    if (!cam->invertible) { /* Ray::new(ORIGIN, ORIGIN) */
+        r.origin = point(0., 0., 0.);
+        r.direction = point(0., 0., 0.);
+        return r;
+    }
+    tup pixel = mat_tuple(cam->inverse, point(world_x, world_y, -1.));
+    tup origin = mat_tuple(cam->inverse, point(0., 0., 0.));
+    r.origin = origin;
+    r.direction = normalize(tsub(pixel, origin));
+    return r;
+}
+
+/* ================================================================ exported test API */
+static ray_t mk_ray(const double* o, const double* dd) {
+    ray_t r = {point(o[0], o[1], o[2]), vector(dd[0], dd[1], dd[2])};
+    return r;
+}
+
+/* Camera::render (src/camera.rs:62-74).  stride > 1 renders only pixels with x % stride == 0 && y % stride == 0
+ * (the CPU-baseline sample); everything else stays 0. */
+int orc_render(const rt_scene_desc* d, const rt_camera_desc* cam, int depth, int stride, double* rgb, int32_t* hit_id,
+               uint8_t* flags, orc_stats* stats) {
+    if (!d || !cam || !rgb || cam->hsize < 1 || cam->vsize < 1 || stride < 1) return RT_ERR_BAD_ARG;
+    memset(&g_stats, 0, sizeof g_stats);
+    size_t npx = (size_t)cam->hsize * (size_t)cam->vsize;
+    memset(rgb, 0, npx * 3 * sizeof(double)); /* Canvas::new: all BLACK */
+    if (hit_id) memset(hit_id, 0, npx * sizeof(int32_t));
+    if (flags) memset(flags, 0, npx);
+    for (int y = 0; y < cam->vsize - 1; y += stride) {      /* 0..vsize-1: last row skipped  */
+        for (int x = 0; x < cam->hsize - 1; x += stride) {  /* 0..hsize-1: last column skipped */
+            ray_t r = ray_for_pixel(cam, (unsigned)x, (unsigned)y);
+            g_flags = 0;
+            g_stats.rays_primary++;
+            int id = 0;
+            col c = color_at(d, r, depth, &id);
+            size_t i = (size_t)y * (size_t)cam->hsize + (size_t)x;
+            rgb[3 * i] = c.r; rgb[3 * i + 1] = c.g; rgb[3 * i + 2] = c.b;
+            if (hit_id) hit_id[i] = id;
+            if (flags) flags[i] = (uint8_t)g_flags;
+        }
+    }
+    if (stats) *stats = g_stats;
+    return RT_OK;
+}
+
+int orc_color_at(const rt_scene_desc* d, int64_t n, const double* origins, const double* dirs, int remaining,
+                 double* rgb, int32_t* hit_id, uint8_t* flags) {
+    if (!d || !origins || !dirs || !rgb || n < 0) return RT_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        g_flags = 0;
+        int id = 0;
+        col c = color_at(d, mk_ray(origins + 3 * i, dirs + 3 * i), remaining, &id);
+        rgb[3 * i] = c.r; rgb[3 * i + 1] = c.g; rgb[3 * i + 2] = c.b;
+        if (hit_id) hit_id[i] = id;
+        if (flags) flags[i] = (uint8_t)g_flags;
+    }
+    return RT_OK;
+}
+
+int orc_intersect_world(const rt_scene_desc* d, int64_t n, const double* origins, const double* dirs, int max_hits,
+                        int32_t* count, double* t_out, int32_t* id_out) {
+    if (!d || !origins || !dirs || !count || n < 0 || max_hits < 0) return RT_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        ilist xs;
+        il_init(&xs);
+        intersect_world(d, mk_ray(origins + 3 * i, dirs + 3 * i), &xs);
+        count[i] = xs.n;
+        for (int k = 0; k < xs.n && k < max_hits; ++k) {
+            if (t_out) t_out[i * max_hits + k] = xs.v[k].t;
+            if (id_out) id_out[i * max_hits + k] = d->node_object_id[xs.v[k].node];
+        }
+        il_free(&xs);
+    }
+    return RT_OK;
+}
+
+int orc_is_shadowed(const rt_scene_desc* d, int64_t n, const double* points, uint8_t* out) {
+    if (!d || !points || !out || n < 0) return RT_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n; ++i)
+        for (int l = 0; l < d->n_lights; ++l)
+            out[i * d->n_lights + l] = (uint8_t)is_shadowed_one(d, point(points[3 * i], points[3 * i + 1], points[3 * i + 2]), l);
+    return RT_OK;
+}
+
+int orc_ray_for_pixel(const rt_camera_desc* cam, int64_t n, const int32_t* px, const int32_t* py, double* origins,
+                      double* dirs) {
+    if (!cam || !px || !py || !origins || !dirs) return RT_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        ray_t r = ray_for_pixel(cam, (unsigned)px[i], (unsigned)py[i]);
+        origins[4 * i] = r.origin.x; origins[4 * i + 1] = r.origin.y; origins[4 * i + 2] = r.origin.z; origins[4 * i + 3] = r.origin.w;
+        dirs[4 * i] = r.direction.x; dirs[4 * i + 1] = r.direction.y; dirs[4 * i + 2] = r.direction.z; dirs[4 * i + 3] = r.direction.w;
+    }
+    return RT_OK;
+}
+
+/* Evaluate one step of the path on a HAND-MADE intersection list (the reference's unit tests build such lists
+ * with the intersections! macro, src/intersection.rs:118-130, which also sorts them).
+ *   what: 0 prepare_computations only, 1 shade_hit, 2 reflected_color, 3 refracted_color, 4 schlick
+ *   comps_out [27] = t, point xyz, eye xyz, normal xyz, inside, over xyz, under xyz, reflect xyz, n1, n2, pad...
+ *   value_out [3]  = colour (what 1-3) or {schlick, 0, 0} */
+int orc_eval_list(const rt_scene_desc* d, const double* origin, const double* dir, int n, const double* t,
+                  const int32_t* node, const double* u, const double* v, int hit, int remaining, int what,
+                  double* comps_out, double* value_out) {
+    if (!d || !origin || !dir || n < 1 || !t || !node || hit < 0 || hit >= n) return RT_ERR_BAD_ARG;
+    ilist xs;
+    il_init(&xs);
+    for (int i = 0; i < n; ++i) {
+        isect x = {t[i], node[i], u != NULL && v != NULL && !isnan(u[i]), u ? u[i] : 0., v ? v[i] : 0.};
+        il_push(&xs, x);
+    }
+    isect self = xs.v[hit];
+    il_sort(&xs);
+    g_flags = 0;
+    ray_t r = mk_ray(origin, dir);
+    comps_t c = prepare_computations(d, &self, r, &xs);
+    il_free(&xs);
+    if (comps_out) {
+        double o[27] = {c.t, c.point.x, c.point.y, c.point.z, c.eye_vector.x, c.eye_vector.y, c.eye_vector.z,
+                        c.normal_vector.x, c.normal_vector.y, c.normal_vector.z, (double)c.inside,
+                        c.over_point.x, c.over_point.y, c.over_point.z, c.under_point.x, c.under_point.y, c.under_point.z,
+                        c.reflect_vector.x, c.reflect_vector.y, c.reflect_vector.z, c.n1, c.n2, (double)g_flags, 0, 0, 0, 0};
+        memcpy(comps_out, o, sizeof o);
+    }
+    if (value_out) {
+        col out = BLACK;
+        if (what == 1) out = shade_hit(d, &c, remaining);
+        else if (what == 2) out = reflected_color(d, &c, remaining);
+        else if (what == 3) out = refracted_color(d, &c, remaining);
+        else if (what == 4) out = C(schlick(&c), 0., 0.);
+        value_out[0] = out.r; value_out[1] = out.g; value_out[2] = out.b;
+    }
+    return RT_OK;
+}
+
+/* Material::lighting (src/material.rs:97-129) on explicit arguments, for the lighting KATs. */
+int orc_lighting(const rt_scene_desc* d, int node, int light, const double* pt, const double* eye, const double* normal,
+                 int in_shadow, double* rgb) {
+    if (!d || node < 0 || node >= d->n_nodes || light < 0 || light >= d->n_lights) return RT_ERR_BAD_ARG;
+    col c = lighting(d, node, light, point(pt[0], pt[1], pt[2]), vector(eye[0], eye[1], eye[2]),
+                     vector(normal[0], normal[1], normal[2]), in_shadow);
+    rgb[0] = c.r; rgb[1] = c.g; rgb[2] = c.b;
+    return RT_OK;
+}
+
+/* Shape::normal_at (src/shape.rs:92-108) for a leaf node; u,v are those of the `hit` argument (NaN = None). */
+int orc_normal_at(const rt_scene_desc* d, int node, const double* world_point, double u, double v, double* out3) {
+    if (!d || node < 0 || node >= d->n_nodes) return RT_ERR_BAD_ARG;
+    isect first = {0., node, !isnan(u), u, v};
+    g_flags = 0;
+    tup n = normal_at(d, node, point(world_point[0], world_point[1], world_point[2]), &first, &first);
+    out3[0] = n.x; out3[1] = n.y; out3[2] = n.z;
+    return RT_OK;
+}
+
+/* Shape::world_to_object / normal_to_world (src/shape.rs:394-420) for the parent-chain KATs. */
+int orc_world_to_object(const rt_scene_desc* d, int node, const double* p, double* out3) {
+    tup r = world_to_object(d, node, point(p[0], p[1], p[2]));
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+    return RT_OK;
+}
+int orc_normal_to_world(const rt_scene_desc* d, int node, const double* n, double* out3) {
+    tup r = normal_to_world(d, node, vector(n[0], n[1], n[2]));
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+    return RT_OK;
+}
+
+/* Pattern::pattern_at_shape (src/pattern.rs:23-35). */
+int orc_pattern_at_shape(const rt_scene_desc* d, int pattern, int node, const double* p, double* rgb) {
+    col c = pattern_at_shape(d, pattern, node, point(p[0], p[1], p[2]));
+    rgb[0] = c.r; rgb[1] = c.g; rgb[2] = c.b;
+    return RT_OK;
+}
+
+/* Bound::intersects (src/bound.rs:85-98) on an explicit box, for the AABB KAT tables. */
+int orc_bound_intersects(const double* box6, const double* origin, const double* dir) {
+    return bound_intersects(box6, mk_ray(origin, dir));
+}
+
+/* CSG::intersection_allowed (src/csg.rs:95-104) for the truth-table KAT. */
+int orc_intersection_allowed(int op, int left_hit, int inside_left, int inside_right) {
+    return intersection_allowed(op, left_hit, inside_left, inside_right);
+}
+
+/* Local-space intersect of a single leaf node (e.g. Sphere::intersect), for the primitive KAT tables:
+ * the ray is used as given (no transform).  Returns the hit count; t_out gets up to 4 values in push order. */
+int orc_local_intersect(const rt_scene_desc* d, int node, const double* origin, const double* dir, double* t_out,
+                        double* uv_out) {
+    ilist xs;
+    il_init(&xs);
+    ray_t r = mk_ray(origin, dir);
+    switch (d->node_kind[node]) {
+        case RT_SPHERE: sphere_intersect(node, r, &xs); break;
+        case RT_PLANE: plane_intersect(node, r, &xs); break;
+        case RT_CUBE: cube_intersect(node, r, &xs); break;
+        case RT_CYLINDER: cylinder_intersect(d, node, r, &xs); break;
+        case RT_CONE: cone_intersect(d, node, r, &xs); break;
+        case RT_TRIANGLE:
+        case RT_SMOOTH_TRIANGLE: triangle_intersect(d, node, r, &xs); break;
+        default: break;
+    }
+    int n = xs.n;
+    for (int i = 0; i < n && i < 4; ++i) {
+        t_out[i] = xs.v[i].t;
+        if (uv_out) { uv_out[2 * i] = xs.v[i].u; uv_out[2 * i + 1] = xs.v[i].v; }
+    }
+    il_free(&xs);
+    return n;
+}
+
+/* Local-space normal of a leaf (e.g. Cube::normal_at), for the primitive KAT tables. */
+int orc_local_normal_at(const rt_scene_desc* d, int node, const double* p, double u, double v, double* out3) {
+    isect first = {0., node, !isnan(u), u, v};
+    tup n = local_normal_at(d, node, point(p[0], p[1], p[2]), &first, &first);
+    out3[0] = n.x; out3[1] = n.y; out3[2] = n.z;
+    return RT_OK;
+}
