@@ -277,6 +277,11 @@ int rt_intersect_world(rt_scene* scene, int64_t n_rays, const double* origins, c
 /* World::is_shadowed (src/world.rs:92-107) for a batch of points: out [n_points][n_lights], 1 = shadowed. */
 int rt_is_shadowed(rt_scene* scene, int64_t n_points, const double* points, uint8_t* out);
 
+/* Camera::ray_for_pixel (src/camera.rs:37-60) for a batch of pixels, evaluated by the device ray-generation
+ * code on device 0: origins_out / directions_out [n][3] (host). */
+int rt_ray_for_pixel(const rt_camera_desc* camera, int64_t n, const int32_t* px, const int32_t* py, double* origins_out,
+                     double* directions_out);
+
 /* Text of the last error on this thread ("" if none). */
 const char* rt_last_error(void);
 

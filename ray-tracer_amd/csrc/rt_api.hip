@@ -1,0 +1,635 @@
+// rt_api.hip — the C ABI of include/rt_abi.h: scene upload, the per-level wavefront pipeline, outputs.
+//
+// The product path is HIP only.  There is no CPU implementation behind these entry points: without a gfx950
+// device every call that would compute fails with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+#include "rt_kernels.hip.h"
+
+using namespace rt;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+extern "C" void rt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* rt_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ scene
+struct LevelStore {
+    void* block = nullptr;
+    long long cap = 0;
+    Level L{};
+};
+
+struct GrowBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct rt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DScene ds{};
+    std::vector<void*> allocs;
+    bool has_csg = false, has_smooth = false;
+    int n_lights = 0;
+    std::vector<LevelStore> levels;
+    unsigned long long* d_counters = nullptr;
+    unsigned long long* h_counters = nullptr;  // pinned
+    GrowBuf out_rgb, out_id, out_flags, frame_rgb, frame_id, frame_flags, in_a, in_b, misc_a, misc_b, misc_c;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+int grow(GrowBuf& b, size_t bytes) {
+    if (bytes <= b.bytes) return RT_OK;
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return RT_OK;
+}
+
+template <class T>
+int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    s->allocs.push_back(p);
+    if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+template <class T>
+std::vector<T> vec_of(const T* p, size_t n) {
+    return p && n ? std::vector<T>(p, p + n) : std::vector<T>();
+}
+
+// rows 0..2 of each 4x4
+std::vector<double> rows3(const double* m16, int n) {
+    std::vector<double> out(size_t(n) * 12);
+    for (int i = 0; i < n; ++i) std::memcpy(&out[size_t(i) * 12], m16 + size_t(i) * 16, 12 * sizeof(double));
+    return out;
+}
+
+int ensure_level(rt_scene* s, size_t idx, long long cap) {
+    if (s->levels.size() <= idx) s->levels.resize(idx + 1);
+    s->levels.reserve(64);
+    LevelStore& ls = s->levels[idx];
+    if (ls.cap >= cap && ls.block) return RT_OK;
+    if (ls.block) HIP_TRY(hipFree(ls.block));
+    ls.block = nullptr;
+    ls.cap = 0;
+    long long c = cap + cap / 8 + 1024;
+    c = (c + 63) & ~63ll;
+    const size_t nd = 18, ni = 4;
+    size_t bytes = size_t(c) * (nd * sizeof(double) + ni * sizeof(int32_t) + 1);
+    HIP_TRY(hipMalloc(&ls.block, bytes));
+    double* dp = static_cast<double*>(ls.block);
+    double** dfields[nd] = {&ls.L.ox, &ls.L.oy, &ls.L.oz, &ls.L.dx, &ls.L.dy, &ls.L.dz, &ls.L.ht, &ls.L.hu, &ls.L.hv,
+                            &ls.L.sr, &ls.L.sg, &ls.L.sb, &ls.L.k_refl, &ls.L.k_transp, &ls.L.k_schlick, &ls.L.cr,
+                            &ls.L.cg, &ls.L.cb};
+    for (size_t k = 0; k < nd; ++k) *dfields[k] = dp + size_t(c) * k;
+    int32_t* ip = reinterpret_cast<int32_t*>(dp + size_t(c) * nd);
+    ls.L.hkey = ip;
+    ls.L.mode = ip + size_t(c);
+    ls.L.child_refl = ip + size_t(c) * 2;
+    ls.L.child_refr = ip + size_t(c) * 3;
+    ls.L.flags = reinterpret_cast<uint8_t*>(ip + size_t(c) * ni);
+    ls.cap = c;
+    return RT_OK;
+}
+
+inline unsigned blocks_for(long long n) { return unsigned((n + BLOCK - 1) / BLOCK); }
+
+struct Timer {  // accumulates device time of bracketed launches when enabled
+    rt_scene* s;
+    hipStream_t st;
+    bool on;
+    double* acc = nullptr;
+    void begin(double* a) {
+        if (!on) return;
+        acc = a;
+        (void)hipEventRecord(s->ev[0], st);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(s->ev[1], st);
+        (void)hipEventSynchronize(s->ev[1]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
+        *acc += double(ms);
+    }
+};
+
+template <bool COUNT>
+void launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+    dim3 g(blocks_for(n)), b(BLOCK);
+    if (s->has_csg) {
+        if (s->has_smooth) hipLaunchKernelGGL((k_trace<true, true, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
+        else hipLaunchKernelGGL((k_trace<true, false, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
+    } else {
+        if (s->has_smooth) hipLaunchKernelGGL((k_trace<false, true, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
+        else hipLaunchKernelGGL((k_trace<false, false, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
+    }
+}
+template <bool COUNT>
+void launch_shade(rt_scene* s, hipStream_t st, const Level& L, const Level& N, long long n, int remaining, long long cap) {
+    dim3 g(blocks_for(n)), b(BLOCK);
+    if (s->has_csg) hipLaunchKernelGGL((k_shade<true, COUNT>), g, b, 0, st, s->ds, L, N, n, remaining, cap, s->d_counters);
+    else hipLaunchKernelGGL((k_shade<false, COUNT>), g, b, 0, st, s->ds, L, N, n, remaining, cap, s->d_counters);
+}
+
+// color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
+int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool counters, rt_stats* stats) {
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), st));
+    Timer tm{s, st, stats != nullptr};
+    std::vector<long long> counts;
+    long long n = n0;
+    for (int d = 0; n > 0; ++d) {
+        const int remaining = max_depth - d;
+        long long next_cap = 0;
+        if (remaining > 0) {
+            next_cap = 2 * n;
+            int rc = ensure_level(s, size_t(d) + 1, next_cap);
+            if (rc != RT_OK) return rc;
+        }
+        const Level& L = s->levels[size_t(d)].L;
+        const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
+        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, sizeof(unsigned long long), st));
+        tm.begin(stats ? &stats->ms_trace : nullptr);
+        if (counters) launch_trace<true>(s, st, L, n); else launch_trace<false>(s, st, L, n);
+        tm.end();
+        if (stats) stats->n_trace_launches++;
+        tm.begin(stats ? &stats->ms_shade : nullptr);
+        if (counters) launch_shade<true>(s, st, L, N, n, remaining, next_cap);
+        else launch_shade<false>(s, st, L, N, n, remaining, next_cap);
+        tm.end();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        counts.push_back(n);
+        long long next = (long long)s->h_counters[CNT_NEXT];
+        if (next > next_cap) {
+            rt_set_error("internal: level %d spawned %lld rays into a queue of %lld", d, next, next_cap);
+            return RT_ERR_OVERFLOW;
+        }
+        n = next;
+    }
+    tm.begin(stats ? &stats->ms_resolve : nullptr);
+    for (int d = int(counts.size()) - 1; d >= 0; --d) {
+        bool has_next = d + 1 < int(counts.size());
+        const Level& L = s->levels[size_t(d)].L;
+        const Level& N = has_next ? s->levels[size_t(d) + 1].L : L;
+        hipLaunchKernelGGL(k_resolve, dim3(blocks_for(counts[size_t(d)])), dim3(BLOCK), 0, st, L, N, counts[size_t(d)],
+                           has_next ? 1 : 0);
+    }
+    tm.end();
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        const unsigned long long* c = s->h_counters;
+        stats->rays_reflect = (int64_t)c[CNT_REFLECT];
+        stats->rays_refract = (int64_t)c[CNT_REFRACT];
+        stats->shaded_nodes = (int64_t)c[CNT_SHADED];
+        stats->rays_shadow = (int64_t)c[CNT_SHADED] * s->n_lights;
+        stats->rays_container = (int64_t)c[CNT_CONTAINER];
+        stats->levels = int32_t(counts.size());
+        stats->work_xforms = (int64_t)c[CNT_W_XFORMS];
+        stats->work_box_tests = (int64_t)c[CNT_W_BOX];
+        stats->work_gate_tests = (int64_t)c[CNT_W_GATE];
+        stats->work_tri_tests = (int64_t)c[CNT_W_TRI];
+        stats->work_tri_det_rej = (int64_t)c[CNT_W_TRI_DET];
+        stats->work_tri_u_rej = (int64_t)c[CNT_W_TRI_U];
+        stats->work_tri_v_rej = (int64_t)c[CNT_W_TRI_V];
+        for (int k = 0; k < 5; ++k) stats->work_prim_tests[k] = (int64_t)c[CNT_W_PRIM0 + k];
+        stats->work_bvh_nodes = (int64_t)c[CNT_W_BVH_NODES];
+    }
+    return RT_OK;
+}
+
+int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams& c, long long& n_slots, long long& n_valid) {
+    if (!cam) { rt_set_error("null camera"); return RT_ERR_BAD_ARG; }
+    if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive (the reference underflows at 0, src/camera.rs:65-66)"); return RT_ERR_BAD_ARG; }
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) { rt_set_error("bad shard %d of %d", rank, n_ranks); return RT_ERR_BAD_ARG; }
+    if (!cam->invertible) {
+        rt_set_error("camera transform is not invertible: the reference then traces Ray(ORIGIN, ORIGIN) for every pixel "
+                     "(src/camera.rs:44-46), a point used as a direction, which the w-free device tuples do not represent");
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (!(cam->inverse[12] == 0. && cam->inverse[13] == 0. && cam->inverse[14] == 0. && cam->inverse[15] == 1.)) {
+        rt_set_error("camera inverse is not affine");
+        return RT_ERR_UNSUPPORTED;
+    }
+    std::memcpy(c.inv, cam->inverse, sizeof c.inv);
+    c.half_width = cam->half_width;
+    c.half_height = cam->half_height;
+    c.pixel_size = cam->pixel_size;
+    c.hsize = cam->hsize;
+    c.vsize = cam->vsize;
+    int W = cam->hsize - 1, H = cam->vsize - 1;
+    c.tiles_x = (W + 7) / 8;
+    c.tiles_y = (H + 7) / 8;
+    c.rank = rank;
+    c.n_ranks = n_ranks;
+    long long tiles = (long long)c.tiles_x * c.tiles_y;
+    long long local_tiles = tiles > rank ? (tiles - rank + n_ranks - 1) / n_ranks : 0;
+    n_slots = local_tiles * 64;
+    n_valid = 0;
+    if (n_ranks == 1) n_valid = (long long)W * H;
+    else {
+        for (long long t = rank; t < tiles; t += n_ranks) {
+            int ty = int(t / c.tiles_x), tx = int(t % c.tiles_x);
+            int w = std::min(8, W - tx * 8), h = std::min(8, H - ty * 8);
+            n_valid += (long long)w * h;
+        }
+    }
+    return RT_OK;
+}
+
+int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb,
+                      int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots) {
+    long long n_valid = 0;
+    int rc = camera_params(cam, opts->rank, opts->n_ranks, c, n_slots, n_valid);
+    if (rc != RT_OK) return rc;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->rays_primary = n_valid;
+    }
+    if (n_slots == 0) return RT_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    rc = ensure_level(s, 0, n_slots);
+    if (rc != RT_OK) return rc;
+    Timer tm{s, st, stats != nullptr};
+    tm.begin(stats ? &stats->ms_raygen : nullptr);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots);
+    tm.end();
+    rc = run_levels(s, st, n_slots, opts->max_depth, opts->want_counters != 0, stats);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags);
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        stats->ms_total = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return RT_OK;
+}
+
+bool check_scene(rt_scene* s) {
+    if (!s) { rt_set_error("null scene handle"); return false; }
+    hipError_t e = hipSetDevice(s->device);
+    if (e != hipSuccess) { rt_set_error("hipSetDevice(%d): %s", s->device, hipGetErrorString(e)); return false; }
+    return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+    if (!desc || !out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    *out = nullptr;
+    Program prog;
+    std::string err;
+    int rc = compile_program(*desc, prog, err);
+    if (rc != RT_OK) { rt_set_error("%s", err.c_str()); return rc; }
+    if (prog.max_chain > MAX_CHAIN) { rt_set_error("transform chain deeper than %d levels", MAX_CHAIN); return RT_ERR_UNSUPPORTED; }
+    int ndev = rt_device_count();
+    if (ndev <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { rt_set_error("device %d out of range (have %d)", device, ndev); return RT_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    rt_scene* s = new rt_scene();
+    s->device = device;
+    const rt_scene_desc& d = *desc;
+    auto fail = [&](int code) { rt_scene_destroy(s); return code; };
+#define UP(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return fail(rc_); } while (0)
+    UP(upload(s, vec_of(d.node_kind, size_t(d.n_nodes)), &s->ds.node_kind));
+    UP(upload(s, vec_of(d.node_object_id, size_t(d.n_nodes)), &s->ds.node_object_id));
+    UP(upload(s, vec_of(d.node_material, size_t(d.n_nodes)), &s->ds.node_material));
+    UP(upload(s, vec_of(d.node_eq_class, size_t(d.n_nodes)), &s->ds.node_eq_class));
+    UP(upload(s, vec_of(d.node_param, size_t(d.n_nodes)), &s->ds.node_param));
+    UP(upload(s, prog.node_nchain, &s->ds.node_nchain));
+    UP(upload(s, vec_of(d.node_casts_shadow, size_t(d.n_nodes)), &s->ds.node_casts_shadow));
+    UP(upload(s, rows3(d.xform_inverse, d.n_xforms), &s->ds.xf));
+    UP(upload(s, vec_of(d.group_box, size_t(d.n_groups) * 6), &s->ds.group_box));
+    {
+        std::vector<double> conic(size_t(d.n_conics) * 2);
+        for (int i = 0; i < d.n_conics; ++i) { conic[2 * size_t(i)] = d.conic_minimum[i]; conic[2 * size_t(i) + 1] = d.conic_maximum[i]; }
+        UP(upload(s, conic, &s->ds.conic));
+        UP(upload(s, vec_of(d.conic_closed, size_t(d.n_conics)), &s->ds.conic_closed));
+    }
+    {
+        std::vector<double> tri(size_t(d.n_triangles) * 12);
+        for (int i = 0; i < d.n_triangles; ++i)
+            for (int k = 0; k < 3; ++k) {
+                tri[size_t(i) * 12 + k] = d.tri_p1[3 * size_t(i) + k];
+                tri[size_t(i) * 12 + 3 + k] = d.tri_e1[3 * size_t(i) + k];
+                tri[size_t(i) * 12 + 6 + k] = d.tri_e2[3 * size_t(i) + k];
+                tri[size_t(i) * 12 + 9 + k] = d.tri_normal[3 * size_t(i) + k];
+            }
+        UP(upload(s, tri, &s->ds.tri));
+        UP(upload(s, vec_of(d.tri_smooth, size_t(d.n_triangles)), &s->ds.tri_smooth));
+        std::vector<double> sm(size_t(d.n_smooth) * 9);
+        for (int i = 0; i < d.n_smooth; ++i)
+            for (int k = 0; k < 3; ++k) {
+                sm[size_t(i) * 9 + k] = d.smooth_n1[3 * size_t(i) + k];
+                sm[size_t(i) * 9 + 3 + k] = d.smooth_n2[3 * size_t(i) + k];
+                sm[size_t(i) * 9 + 6 + k] = d.smooth_n3[3 * size_t(i) + k];
+            }
+        UP(upload(s, sm, &s->ds.smooth));
+    }
+    UP(upload(s, vec_of(d.material_params, size_t(d.n_materials) * RT_MAT_STRIDE), &s->ds.mat));
+    UP(upload(s, vec_of(d.material_pattern, size_t(d.n_materials)), &s->ds.mat_pattern));
+    UP(upload(s, vec_of(d.pattern_kind, size_t(d.n_patterns)), &s->ds.pat_kind));
+    {
+        std::vector<double> ab(size_t(d.n_patterns) * 6);
+        for (int i = 0; i < d.n_patterns; ++i)
+            for (int k = 0; k < 3; ++k) { ab[size_t(i) * 6 + k] = d.pattern_a[3 * size_t(i) + k]; ab[size_t(i) * 6 + 3 + k] = d.pattern_b[3 * size_t(i) + k]; }
+        UP(upload(s, ab, &s->ds.pat_ab));
+        UP(upload(s, rows3(d.pattern_inverse, d.n_patterns), &s->ds.pat_inv));
+        std::vector<double> li(size_t(d.n_lights) * 6);
+        for (int i = 0; i < d.n_lights; ++i)
+            for (int k = 0; k < 3; ++k) { li[size_t(i) * 6 + k] = d.light_position[3 * size_t(i) + k]; li[size_t(i) * 6 + 3 + k] = d.light_intensity[3 * size_t(i) + k]; }
+        UP(upload(s, li, &s->ds.light));
+    }
+    UP(upload(s, prog.items, &s->ds.items));
+    UP(upload(s, prog.chain_pool, &s->ds.chain_pool));
+    UP(upload(s, prog.bvh, &s->ds.bvh));
+    UP(upload(s, prog.mesh_tris, &s->ds.mesh_tris));
+#undef UP
+    s->ds.n_lights = d.n_lights;
+    s->ds.n_nodes = d.n_nodes;
+    s->ds.n_items = int32_t(prog.items.size());
+    s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
+    s->has_csg = prog.has_csg;
+    s->has_smooth = prog.has_smooth;
+    s->n_lights = d.n_lights;
+    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&s->ev[0]) != hipSuccess || hipEventCreate(&s->ev[1]) != hipSuccess) {
+        rt_set_error("could not create stream / counters: %s", hipGetErrorString(hipGetLastError()));
+        return fail(RT_ERR_HIP);
+    }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void* p : s->allocs) (void)hipFree(p);
+    for (LevelStore& l : s->levels)
+        if (l.block) (void)hipFree(l.block);
+    for (GrowBuf* b : {&s->out_rgb, &s->out_id, &s->out_flags, &s->frame_rgb, &s->frame_id, &s->frame_flags, &s->in_a, &s->in_b,
+                       &s->misc_a, &s->misc_b, &s->misc_c})
+        if (b->p) (void)hipFree(b->p);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
+    if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
+    if (s->ev[1]) (void)hipEventDestroy(s->ev[1]);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int64_t rt_shard_pixel_count(const rt_camera_desc* cam, int32_t rank, int32_t n_ranks) {
+    if (!cam || cam->hsize < 1 || cam->vsize < 1 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return RT_ERR_BAD_ARG;
+    long long tiles = (long long)((cam->hsize - 1 + 7) / 8) * ((cam->vsize - 1 + 7) / 8);
+    long long local_tiles = tiles > rank ? (tiles - rank + n_ranks - 1) / n_ranks : 0;
+    return local_tiles * 64;
+}
+
+int rt_render_shard(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_out, int32_t* d_hit_id_out,
+                    uint8_t* d_flags_out, rt_stats* stats) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !d_rgb_out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = opts->stream ? static_cast<hipStream_t>(opts->stream) : s->stream;
+    CameraParams c;
+    long long n_slots = 0;
+    int rc = render_shard_impl(s, cam, opts, st, d_rgb_out, d_hit_id_out, d_flags_out, stats, c, n_slots);
+    if (rc != RT_OK) return rc;
+    if (!opts->stream) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_assemble(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const double* d_rgb_shards, const int32_t* d_id_shards,
+                double* d_rgb_frame, int32_t* d_id_frame, void* stream) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!cam || !d_rgb_shards || !d_rgb_frame) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
+    HIP_TRY(hipMemsetAsync(d_rgb_frame, 0, npx * 3 * sizeof(double), st));
+    if (d_id_frame) HIP_TRY(hipMemsetAsync(d_id_frame, 0, npx * sizeof(int32_t), st));
+    long long off = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        CameraParams c;
+        long long n_slots = 0, n_valid = 0;
+        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid);
+        if (rc != RT_OK) return rc;
+        if (n_slots)
+            hipLaunchKernelGGL(k_assemble, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, d_rgb_shards + 3 * off,
+                               d_id_shards ? d_id_shards + off : nullptr, (const uint8_t*)nullptr, d_rgb_frame, d_id_frame,
+                               (uint8_t*)nullptr);
+        off += n_slots;
+    }
+    HIP_TRY(hipGetLastError());
+    if (!stream) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
+              uint8_t* flags_out, rt_stats* stats) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !rgb_out || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = opts->stream ? static_cast<hipStream_t>(opts->stream) : s->stream;
+    long long n_slots = rt_shard_pixel_count(cam, opts->rank, opts->n_ranks);
+    if (n_slots < 0) { rt_set_error("bad camera size or shard"); return RT_ERR_BAD_ARG; }
+    size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
+    int rc;
+    if ((rc = grow(s->out_rgb, size_t(n_slots) * 3 * sizeof(double))) != RT_OK) return rc;
+    if ((rc = grow(s->out_id, size_t(n_slots) * sizeof(int32_t))) != RT_OK) return rc;
+    if ((rc = grow(s->out_flags, size_t(n_slots))) != RT_OK) return rc;
+    if ((rc = grow(s->frame_rgb, npx * 3 * sizeof(double))) != RT_OK) return rc;
+    if ((rc = grow(s->frame_id, npx * sizeof(int32_t))) != RT_OK) return rc;
+    if ((rc = grow(s->frame_flags, npx)) != RT_OK) return rc;
+    CameraParams c;
+    rc = render_shard_impl(s, cam, opts, st, static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p),
+                           static_cast<uint8_t*>(s->out_flags.p), stats, c, n_slots);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->frame_rgb.p, 0, npx * 3 * sizeof(double), st));  // Canvas::new: all BLACK
+    HIP_TRY(hipMemsetAsync(s->frame_id.p, 0, npx * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(s->frame_flags.p, 0, npx, st));
+    if (n_slots)
+        hipLaunchKernelGGL(k_assemble, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, static_cast<const double*>(s->out_rgb.p),
+                           static_cast<const int32_t*>(s->out_id.p), static_cast<const uint8_t*>(s->out_flags.p),
+                           static_cast<double*>(s->frame_rgb.p), static_cast<int32_t*>(s->frame_id.p), static_cast<uint8_t*>(s->frame_flags.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->frame_rgb.p, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->frame_id.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->frame_flags.p, npx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t remaining, double* rgb_out,
+                int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n_rays < 0 || !origins || !directions || !rgb_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    if (stats) { std::memset(stats, 0, sizeof *stats); stats->rays_primary = n_rays; }
+    if (n_rays == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    int rc;
+    size_t rb = size_t(n_rays) * 3 * sizeof(double);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->out_rgb, rb)) != RT_OK ||
+        (rc = grow(s->out_id, size_t(n_rays) * sizeof(int32_t))) != RT_OK || (rc = grow(s->out_flags, size_t(n_rays))) != RT_OK)
+        return rc;
+    if ((rc = ensure_level(s, 0, n_rays)) != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_load_rays, dim3(blocks_for(n_rays)), dim3(BLOCK), 0, st, s->levels[0].L, (long long)n_rays,
+                       static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p));
+    rc = run_levels(s, st, n_rays, remaining, false, stats);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(k_output, dim3(blocks_for(n_rays)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, (long long)n_rays,
+                       static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p), static_cast<uint8_t*>(s->out_flags.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
+    if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->out_id.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->out_flags.p, size_t(n_rays), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t max_hits,
+                       int32_t* count_out, double* t_out, int32_t* object_id_out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n_rays < 0 || !origins || !directions || !count_out || !t_out || !object_id_out || max_hits < 1) {
+        rt_set_error("null argument, negative count or max_hits < 1");
+        return RT_ERR_BAD_ARG;
+    }
+    if (n_rays == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    int rc;
+    size_t rb = size_t(n_rays) * 3 * sizeof(double);
+    size_t lb = size_t(n_rays) * size_t(max_hits);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->misc_a, size_t(n_rays) * sizeof(int32_t))) != RT_OK ||
+        (rc = grow(s->misc_b, lb * sizeof(double))) != RT_OK || (rc = grow(s->misc_c, lb * sizeof(int32_t))) != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->misc_b.p, 0, lb * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(s->misc_c.p, 0, lb * sizeof(int32_t), st));
+    dim3 g(blocks_for(n_rays)), b(BLOCK);
+    if (s->has_csg)
+        hipLaunchKernelGGL((k_list<true>), g, b, 0, st, s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+                           static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
+                           static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+    else
+        hipLaunchKernelGGL((k_list<false>), g, b, 0, st, s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+                           static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
+                           static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(count_out, s->misc_a.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t_out, s->misc_b.p, lb * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(object_id_out, s->misc_c.p, lb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < n_rays; ++i)
+        if (count_out[i] > LIST_CAP) {
+            rt_set_error("ray %lld has %d intersections; the device list holds %d", (long long)i, count_out[i], LIST_CAP);
+            return RT_ERR_OVERFLOW;
+        }
+    return RT_OK;
+}
+
+int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t* out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n_points < 0 || !points || !out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    if (n_points == 0 || s->n_lights == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    int rc;
+    size_t rb = size_t(n_points) * 3 * sizeof(double), ob = size_t(n_points) * size_t(s->n_lights);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->misc_a, ob)) != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
+    dim3 g(blocks_for(n_points)), b(BLOCK);
+    if (s->has_csg)
+        hipLaunchKernelGGL((k_shadow_points<true>), g, b, 0, st, s->ds, (long long)n_points, static_cast<const double*>(s->in_a.p),
+                           static_cast<uint8_t*>(s->misc_a.p));
+    else
+        hipLaunchKernelGGL((k_shadow_points<false>), g, b, 0, st, s->ds, (long long)n_points, static_cast<const double*>(s->in_a.p),
+                           static_cast<uint8_t*>(s->misc_a.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, s->misc_a.p, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_ray_for_pixel(const rt_camera_desc* cam, int64_t n, const int32_t* px, const int32_t* py, double* origins_out,
+                     double* directions_out) {
+    if (n < 0 || !px || !py || !origins_out || !directions_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    CameraParams c;
+    long long n_slots = 0, n_valid = 0;
+    int rc = camera_params(cam, 0, 1, c, n_slots, n_valid);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (rt_device_count() <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(0));
+    int32_t *dpx = nullptr, *dpy = nullptr;
+    double *dor = nullptr, *ddi = nullptr;
+    size_t ib = size_t(n) * sizeof(int32_t), db = size_t(n) * 3 * sizeof(double);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dpx), ib));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dpy), ib));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dor), db));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ddi), db));
+    HIP_TRY(hipMemcpy(dpx, px, ib, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dpy, py, ib, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rays_for_pixels, dim3(blocks_for(n)), dim3(BLOCK), 0, nullptr, c, (long long)n, dpx, dpy, dor, ddi);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(origins_out, dor, db, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(directions_out, ddi, db, hipMemcpyDeviceToHost));
+    (void)hipFree(dpx); (void)hipFree(dpy); (void)hipFree(dor); (void)hipFree(ddi);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// rt_device.h — device-side tables and per-level queues shared by the kernels (rt_kernels.hip) and the
+// orchestration (rt_api.hip).  Plain structs of device pointers, passed to kernels by value.
+#pragma once
+#include <cstdint>
+
+#include "rt_program.h"
+
+namespace rt {
+
+constexpr double EPS = 0.00001;   // EPSILON, src/lib.rs:42
+constexpr int BLOCK = 256;        // 4 wavefronts
+constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
+constexpr int CSG_DEPTH = 8;      // nested CSG levels
+constexpr int LIST_CAP = 64;      // per-ray list for the n1/n2 container walk and rt_intersect_world
+constexpr int CONTAINER_CAP = 32; // `containers` vector of prepare_computations
+constexpr int MAX_CHAIN = 16;     // transform levels above a leaf
+
+// Scene tables in HBM.  SoA per table; rows padded to what one lane fetches at once.
+struct DScene {
+    // nodes (src/shape.rs:25-37)
+    const int32_t* node_kind;
+    const int32_t* node_object_id;
+    const int32_t* node_material;
+    const int32_t* node_eq_class;
+    const int32_t* node_param;
+    const int32_t* node_nchain;       // offset into chain_pool: [len, x_leaf, x_parent, ... x_root]
+    const uint8_t* node_casts_shadow;
+    const double* xf;                 // [n_xforms][12]: rows 0..2 of the inverse (row 3 is 0,0,0,1)
+    const double* group_box;          // [n_groups][6]
+    const double* conic;              // [n_conics][2] minimum, maximum
+    const uint8_t* conic_closed;
+    const double* tri;                // [n_triangles][12] p1, e1, e2, normal
+    const int32_t* tri_smooth;
+    const double* smooth;             // [n_smooth][9] n1, n2, n3
+    const double* mat;                // [n_materials][10]
+    const int32_t* mat_pattern;
+    const int32_t* pat_kind;
+    const double* pat_ab;             // [n_patterns][6] a, b
+    const double* pat_inv;            // [n_patterns][12]
+    const double* light;              // [n_lights][6] position, intensity
+    int32_t n_lights;
+    int32_t n_nodes;
+    // traversal program + acceleration
+    const Item* items;
+    int32_t n_items;
+    const int32_t* chain_pool;
+    const BvhNode* bvh;
+    const MeshTri* mesh_tris;
+    int32_t all_cast_shadow;
+    int32_t _pad;
+};
+
+// One recursion level: the ray queue and, index for index, the nodes of the ray tree at that depth.
+struct Level {
+    double *ox, *oy, *oz, *dx, *dy, *dz;  // ray (origin.x is NaN for a padding slot)
+    double *ht, *hu, *hv;                 // hit t and the (u,v) normal_at must use (F5)
+    int32_t* hkey;                        // node*4 + push index of the hit, -1 = miss
+    double *sr, *sg, *sb;                 // surface colour (sum of Material::lighting over lights)
+    double *k_refl, *k_transp, *k_schlick;  // material.reflective, material.transparency, reflectance
+    int32_t* mode;                        // 1 = Schlick blend (reflective > 0 && transparency > 0)
+    int32_t *child_refl, *child_refr;     // index in the next level or -1 (=> BLACK)
+    double *cr, *cg, *cb;                 // resolved colour of this node
+    uint8_t* flags;
+};
+
+// Device counters (one int64 each).
+enum Counter : int {
+    CNT_NEXT = 0,      // rays appended to the next level
+    CNT_REFLECT,       // reflection rays spawned
+    CNT_REFRACT,       // refraction rays spawned
+    CNT_SHADED,        // nodes that hit something
+    CNT_CONTAINER,     // container-walk list passes
+    CNT_W_XFORMS,
+    CNT_W_BOX,
+    CNT_W_GATE,
+    CNT_W_TRI,
+    CNT_W_TRI_DET,
+    CNT_W_TRI_U,
+    CNT_W_TRI_V,
+    CNT_W_PRIM0,       // +0..4: sphere, plane, cube, cylinder, cone
+    CNT_W_BVH_NODES = CNT_W_PRIM0 + 5,
+    CNT_COUNT
+};
+
+struct CameraParams {
+    double inv[12];
+    double half_width, half_height, pixel_size;
+    int32_t hsize, vsize;
+    int32_t tiles_x, tiles_y;
+    int32_t rank, n_ranks;
+};
+
+}  // namespace rt

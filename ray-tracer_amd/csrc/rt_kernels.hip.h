@@ -1,0 +1,985 @@
+// rt_kernels.hip.h — hand-written gfx950 device code for the render path.  Included once by rt_api.hip.
+//
+// Arithmetic rules: IEEE f64 everywhere, built with -ffp-contract=off, every
+// expression below that restates a reference formula keeps the reference's operand order, sums run left to right,
+// normalisation divides four... three times by the magnitude (never multiplies by a reciprocal), f64::max/min
+// become fmax/fmin (both ignore a NaN operand).  Tuples drop w on the device: rt_scene_create only accepts affine
+// inverses, for which w stays exactly 1 (points) or 0 (vectors) and its terms add exactly 0.0.
+//
+// Execution model: one ray per lane, 256-thread workgroups (4 wavefronts).  A frame is a wavefront pipeline over
+// recursion levels: trace(level) -> shade(level) [shadow + container traversals inline, spawns level+1 with
+// ballot/mbcnt compaction] ... then resolve(level) from the deepest level up, which evaluates shade_hit's blend in
+// the reference's own order (src/world.rs:68-78) so colours match the recursive form bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 v = {x, y, z}; return v; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 vmul(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 vhad(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+// Tuple::dot (src/tuple.rs:45-47); the w term is exactly 0
+__device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+__device__ __forceinline__ double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) {  // src/tuple.rs:36-43
+    double m = magnitude(a);
+    return mk(a.x / m, a.y / m, a.z / m);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {  // src/tuple.rs:49-52
+    return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return vsub(v, vmul(vmul(n, 2.), dot(v, n))); }  // :54-56
+__device__ __forceinline__ bool near_eq(double a, double b) { return fabs(a - b) < EPS; }          // src/lib.rs:56
+
+// Matrix * Tuple (src/matrix.rs:171-200) for an affine matrix given as rows 0..2; point: w = 1, vector: w = 0.
+__device__ __forceinline__ V3 xf_point(const double* __restrict__ m, V3 p) {
+    return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+              ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+}
+__device__ __forceinline__ V3 xf_vector(const double* __restrict__ m, V3 v) {
+    return mk((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+              (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+// inverse.transpose() * vector: row r of the transpose is column r of the inverse
+__device__ __forceinline__ V3 xf_normal(const double* __restrict__ m, V3 v) {
+    return mk((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z,
+              (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Work counters of the instrumented build (rt_render_opts.want_counters); plain registers otherwise unused.
+struct Work {
+    unsigned xforms, box, gate, tri, tri_det, tri_u, tri_v, prim[5], bvh_nodes;
+};
+template <bool COUNT>
+__device__ __forceinline__ void bump(unsigned& c, unsigned n = 1) {
+    if (COUNT) c += n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sinks: what a traversal does with each intersection the reference would have put in its list.
+// key = node * 4 + push index inside the primitive = the reference's emission order.
+
+// Intersection::hit over the sorted list == minimum (t, key) among t > 0 (src/intersection.rs:30-36), and
+// intersections[0] == minimum (t, key) over everything (src/intersection.rs:40).
+template <bool NEED_FIRST>
+struct ClosestSink {
+    double best_t, bu, bv;
+    int best_key;
+    double first_t, fu, fv;
+    int first_key, first_uv;
+    unsigned flags;
+    __device__ __forceinline__ void init(double tmax) {
+        best_t = tmax; best_key = -1; bu = bv = 0.;
+        first_t = INFINITY; first_key = -1; fu = fv = 0.; first_uv = 0;
+        flags = 0;
+    }
+    __device__ __forceinline__ double lo() const { return NEED_FIRST ? -INFINITY : 0.; }
+    __device__ __forceinline__ double hi() const { return best_t; }
+    __device__ __forceinline__ void emit(double t, int key, double u, double v, int uv) {
+        if (t != t) flags |= RT_FLAG_NAN_T;
+        if (t > 0. && (t < best_t || (t == best_t && (best_key < 0 || key < best_key)))) {
+            best_t = t; best_key = key; bu = u; bv = v;
+        }
+        if (NEED_FIRST && (t < first_t || (t == first_t && (first_key < 0 || key < first_key)))) {
+            first_t = t; first_key = key; fu = u; fv = v; first_uv = uv;
+        }
+    }
+};
+
+// Everything with t <= limit or near_eq(t, limit), kept as an unsorted bounded list (sorted by the caller).
+struct ListSink {
+    double* t;    // [LIST_CAP], private
+    int* key;
+    int n;        // true count (may exceed cap)
+    int cap;
+    double limit;
+    unsigned flags;
+    __device__ __forceinline__ double lo() const { return -INFINITY; }
+    __device__ __forceinline__ double hi() const { return limit + 2. * EPS; }
+    __device__ __forceinline__ void emit(double tt, int k, double, double, int) {
+        if (tt != tt) flags |= RT_FLAG_NAN_T;
+        if (tt <= limit || fabs(tt - limit) < EPS) {
+            if (n < cap) { t[n] = tt; key[n] = k; } else flags |= RT_FLAG_LIST_OVERFLOW;
+            ++n;
+        }
+    }
+};
+
+__device__ __forceinline__ bool key_less(double ta, int ka, double tb, int kb) { return ta < tb || (ta == tb && ka < kb); }
+
+// stable sort by t == sort by (t, key): insertion sort on a short private list
+__device__ inline void sort_list(double* t, int* key, int n) {
+    for (int i = 1; i < n; ++i) {
+        double ti = t[i];
+        int ki = key[i];
+        int j = i - 1;
+        while (j >= 0 && key_less(ti, ki, t[j], key[j])) { t[j + 1] = t[j]; key[j + 1] = key[j]; --j; }
+        t[j + 1] = ti;
+        key[j + 1] = ki;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Primitive intersections, each a literal restatement; `E` receives (t, push index, u, v, has_uv).
+
+template <class E>
+__device__ __forceinline__ void isect_sphere(V3 o, V3 d, E&& e) {  // src/sphere.rs:43-63
+    V3 sphere_to_ray = o;  // origin - ORIGIN
+    double a = dot(d, d);
+    double b = 2. * dot(d, sphere_to_ray);
+    double c = dot(sphere_to_ray, sphere_to_ray) - 1.;
+    double discriminant = b * b - 4. * a * c;
+    if (discriminant < 0.) return;
+    double t1 = (-b - sqrt(discriminant)) / (2. * a);
+    double t2 = (-b + sqrt(discriminant)) / (2. * a);
+    e(t1, 0, 0., 0., 0);
+    e(t2, 1, 0., 0., 0);
+}
+
+template <class E>
+__device__ __forceinline__ void isect_plane(V3 o, V3 d, E&& e) {  // src/plane.rs:44-51
+    if (fabs(d.y) < EPS) return;
+    e(-o.y / d.y, 0, 0., 0., 0);
+}
+
+// src/cube.rs:63-79 == src/bound.rs:100-116
+__device__ __forceinline__ void check_axis(double origin, double direction, double minimum, double maximum, double& tmin,
+                                           double& tmax) {
+    double tmin_numerator = minimum - origin;
+    double tmax_numerator = maximum - origin;
+    double a, b;
+    if (fabs(direction) >= EPS) {
+        a = tmin_numerator / direction;
+        b = tmax_numerator / direction;
+    } else {
+        a = tmin_numerator * INFINITY;
+        b = tmax_numerator * INFINITY;
+    }
+    if (a > b) { tmin = b; tmax = a; } else { tmin = a; tmax = b; }
+}
+__device__ __forceinline__ double max3nan(double a, double b, double c) { return fmax(fmax(fmax(NAN, a), b), c); }
+__device__ __forceinline__ double min3nan(double a, double b, double c) { return fmin(fmin(fmin(NAN, a), b), c); }
+
+// the slab test shared by Cube::intersect (src/cube.rs:45-61) and Bound::intersects (src/bound.rs:85-98)
+__device__ __forceinline__ bool slabs(V3 o, V3 d, const double* __restrict__ box, double& tmin, double& tmax) {
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(o.x, d.x, box[0], box[3], xtmin, xtmax);
+    check_axis(o.y, d.y, box[1], box[4], ytmin, ytmax);
+    check_axis(o.z, d.z, box[2], box[5], ztmin, ztmax);
+    tmin = max3nan(xtmin, ytmin, ztmin);
+    tmax = min3nan(xtmax, ytmax, ztmax);
+    return !(tmin > tmax);
+}
+
+template <class E>
+__device__ __forceinline__ void isect_cube(V3 o, V3 d, E&& e) {
+    const double unit[6] = {-1., -1., -1., 1., 1., 1.};
+    double tmin, tmax;
+    if (!slabs(o, d, unit, tmin, tmax)) return;
+    e(tmin, 0, 0., 0., 0);
+    e(tmax, 1, 0., 0., 0);
+}
+
+template <class E>
+__device__ __forceinline__ void isect_cylinder(V3 o, V3 d, double minimum, double maximum, bool closed, E&& e) {
+    // src/cylinder.rs:53-102; push order t0, t1, lower cap, upper cap
+    double a = d.x * d.x + d.z * d.z;
+    if (!near_eq(a, 0.)) {
+        double b = 2. * o.x * d.x + 2. * o.z * d.z;
+        double c = o.x * o.x + o.z * o.z - 1.;
+        double disc = b * b - 4. * a * c;
+        if (disc < 0.) return;  // `return vec![]`: no caps either
+        double t0 = (-b - sqrt(disc)) / (2. * a);
+        double t1 = (-b + sqrt(disc)) / (2. * a);
+        if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+        double y0 = o.y + t0 * d.y;
+        if (minimum < y0 && y0 < maximum) e(t0, 0, 0., 0., 0);
+        double y1 = o.y + t1 * d.y;
+        if (minimum < y1 && y1 < maximum) e(t1, 1, 0., 0., 0);
+    }
+    if (!closed || near_eq(d.y, 0.)) return;
+    double t_lower = (minimum - o.y) / d.y;
+    {
+        double x = o.x + t_lower * d.x, z = o.z + t_lower * d.z;
+        double result = x * x + z * z;
+        if (result < 1. || near_eq(result, 1.)) e(t_lower, 2, 0., 0., 0);
+    }
+    double t_upper = (maximum - o.y) / d.y;
+    {
+        double x = o.x + t_upper * d.x, z = o.z + t_upper * d.z;
+        double result = x * x + z * z;
+        if (result < 1. || near_eq(result, 1.)) e(t_upper, 3, 0., 0., 0);
+    }
+}
+
+template <class E>
+__device__ __forceinline__ void isect_cone(V3 o, V3 d, double minimum, double maximum, bool closed, E&& e) {
+    // src/cone.rs:53-108; push order: linear-case t | t0, t1, then lower cap, upper cap
+    double a = d.x * d.x - d.y * d.y + d.z * d.z;
+    double b = 2. * o.x * d.x - 2. * o.y * d.y + 2. * o.z * d.z;
+    double c = o.x * o.x - o.y * o.y + o.z * o.z;
+    if (near_eq(a, 0.) && !near_eq(b, 0.)) {
+        double t = -c / (2. * b);
+        e(t, 0, 0., 0., 0);
+    }
+    if (!near_eq(a, 0.)) {
+        double disc = b * b - 4. * a * c;
+        if (disc > 0. || near_eq(disc, 0.)) {
+            double t0 = (-b - sqrt(disc)) / (2. * a);
+            double t1 = (-b + sqrt(disc)) / (2. * a);
+            if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+            double y0 = o.y + t0 * d.y;
+            if (minimum < y0 && y0 < maximum) e(t0, 0, 0., 0., 0);
+            double y1 = o.y + t1 * d.y;
+            if (minimum < y1 && y1 < maximum) e(t1, 1, 0., 0., 0);
+        }
+    }
+    if (!closed || near_eq(d.y, 0.)) return;
+    double t_lower = (minimum - o.y) / d.y;
+    {
+        double x = o.x + t_lower * d.x, z = o.z + t_lower * d.z;
+        double result = x * x + z * z;
+        if (result < minimum * minimum || near_eq(result, minimum * minimum)) e(t_lower, 2, 0., 0., 0);
+    }
+    double t_upper = (maximum - o.y) / d.y;
+    {
+        double x = o.x + t_upper * d.x, z = o.z + t_upper * d.z;
+        double result = x * x + z * z;
+        if (result < maximum * maximum || near_eq(result, maximum * maximum)) e(t_upper, 3, 0., 0., 0);
+    }
+}
+
+// Moller-Trumbore exactly as src/triangle.rs:62-87 / src/smooth_triangle.rs:71-96
+template <bool COUNT, class E>
+__device__ __forceinline__ void isect_triangle(V3 o, V3 d, V3 point1, V3 edge_vector1, V3 edge_vector2, int smooth,
+                                               Work& w, E&& e) {
+    bump<COUNT>(w.tri);
+    V3 dir_cross_e2 = cross(d, edge_vector2);
+    double determinant = dot(edge_vector1, dir_cross_e2);
+    if (fabs(determinant) < EPS) { bump<COUNT>(w.tri_det); return; }
+    double f = 1.0 / determinant;
+    V3 p1_to_origin = vsub(o, point1);
+    double u = f * dot(p1_to_origin, dir_cross_e2);
+    if (u < 0. || u > 1.) { bump<COUNT>(w.tri_u); return; }
+    V3 origin_cross_e1 = cross(p1_to_origin, edge_vector1);
+    double v = f * dot(d, origin_cross_e1);
+    if (v < 0. || (u + v) > 1.) { bump<COUNT>(w.tri_v); return; }
+    double t = f * dot(edge_vector2, origin_cross_e1);
+    e(t, 0, u, v, smooth);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Acceleration BVH over one triangle mesh (non-semantic: only decides which triangles get tested).
+// Boxes are padded on the host; the slab test below is deliberately loose (NaN-ignoring min/max, relative slack).
+
+__device__ __forceinline__ bool bvh_box(const double* __restrict__ lo, const double* __restrict__ hi, V3 o, V3 inv,
+                                        double tlo, double thi, double& tnear) {
+    double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+    tnear = tmin;
+    double slack = 1e-9 * (fabs(tmin) + fabs(tmax));
+    if (!(slack == slack) || slack > 1e300) slack = 0.;  // inf - inf bookkeeping: infinities compare fine on their own
+    return !(tmin > tmax + slack) && !(tmax < tlo - slack) && !(tmin > thi + slack);
+}
+
+template <bool COUNT, class Sink, class E>
+__device__ __forceinline__ void bvh_traverse(const DScene& S, int root, V3 o, V3 d, const Sink& sink, bool full_line,
+                                             int* __restrict__ stack, Work& w, E&& e) {
+    V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    const int tid = threadIdx.x;
+    int sp = 0;
+    int cur = root;
+    while (true) {
+        const BvhNode* __restrict__ n = S.bvh + cur;
+        bump<COUNT>(w.bvh_nodes);
+        bump<COUNT>(w.box, 2);
+        double tlo = full_line ? -INFINITY : sink.lo();
+        double thi = sink.hi();
+        double n0, n1;
+        bool h0 = n->c0 != INT32_MIN && bvh_box(n->lo0, n->hi0, o, inv, tlo, thi, n0);
+        bool h1 = n->c1 != INT32_MIN && bvh_box(n->lo1, n->hi1, o, inv, tlo, thi, n1);
+        int c0 = n->c0, c1 = n->c1;
+        if (h0 && h1 && n1 < n0) { int t = c0; c0 = c1; c1 = t; }  // nearer child first
+        else if (!h0 && h1) { c0 = c1; h0 = true; h1 = false; }
+        int next = -1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            bool hit = side == 0 ? h0 : h1;
+            int c = side == 0 ? c0 : c1;
+            if (!hit) continue;
+            if (c >= 0) {
+                if (next < 0) next = c;
+                else stack[sp++ * BLOCK + tid] = c;
+            } else {
+                int code = ~c;
+                int first = code >> 4, count = (code & 15) + 1;
+                for (int i = 0; i < count; ++i) {
+                    const MeshTri* __restrict__ t = S.mesh_tris + first + i;
+                    int node = t->node;
+                    isect_triangle<COUNT>(o, d, mk(t->p1[0], t->p1[1], t->p1[2]), mk(t->e1[0], t->e1[1], t->e1[2]),
+                                          mk(t->e2[0], t->e2[1], t->e2[2]), t->smooth, w,
+                                          [&](double tt, int k, double u, double v, int uv) { e(tt, node * 4 + k, u, v, uv); });
+                }
+            }
+        }
+        if (next >= 0) { cur = next; continue; }
+        if (sp == 0) break;
+        cur = stack[--sp * BLOCK + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Scene traversal == World::intersect_world (src/world.rs:46-55) without materialising the list: every
+// intersection the reference would list is handed to `sink` with its (t, key).
+
+struct CsgScratch {
+    double t[CSG_CAP], u[CSG_CAP], v[CSG_CAP];
+    int key[CSG_CAP];
+    int seg[CSG_DEPTH];
+    int n, depth;
+    unsigned flags;
+};
+
+__device__ __forceinline__ bool csg_allowed(int op, bool left_hit, bool inl, bool inr) {  // src/csg.rs:95-104
+    switch (op) {
+        case RT_CSG_UNION: return (left_hit && !inr) || (!left_hit && !inl);
+        case RT_CSG_INTERSECTION: return (left_hit && inr) || (!left_hit && inl);
+        case RT_CSG_DIFFERENCE: return (left_hit && !inr) || (!left_hit && inl);
+        default: return false;
+    }
+}
+
+__device__ __forceinline__ void apply_chain(const DScene& S, int chain, V3& o, V3& d, unsigned& xforms) {
+    const int* __restrict__ c = S.chain_pool + chain;
+    int len = c[0];
+    for (int i = 1; i <= len; ++i) {  // Ray::transform per level, outermost first (src/shape.rs:75-76, src/ray.rs:25-30)
+        const double* __restrict__ m = S.xf + (size_t)c[i] * 12;
+        o = xf_point(m, o);
+        d = xf_vector(m, d);
+        ++xforms;
+    }
+}
+
+template <bool HAS_CSG, bool COUNT, class Sink>
+__device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& sink, int* __restrict__ stack, Work& w) {
+    CsgScratch* cs = nullptr;
+    CsgScratch cs_storage;
+    if (HAS_CSG) {
+        cs = &cs_storage;
+        cs->n = 0;
+        cs->depth = 0;
+        cs->flags = 0;
+    }
+    auto out = [&](double t, int key, double u, double v, int uv) {
+        if (HAS_CSG && cs->depth > 0) {
+            if (cs->n < CSG_CAP) {
+                int i = cs->n++;
+                cs->t[i] = t; cs->key[i] = key; cs->u[i] = u; cs->v[i] = v;
+                if (uv) cs->key[i] |= (1 << 30);
+            } else {
+                cs->flags |= RT_FLAG_LIST_OVERFLOW;
+            }
+        } else {
+            sink.emit(t, key, u, v, uv);
+        }
+    };
+    int i = 0;
+    const int n_items = S.n_items;
+    while (i < n_items) {
+        const Item it = S.items[i];
+        ++i;
+        if (it.type == ITEM_CSG_BEGIN) {
+            if (HAS_CSG) {
+                if (cs->depth < CSG_DEPTH) cs->seg[cs->depth] = cs->n; else cs->flags |= RT_FLAG_LIST_OVERFLOW;
+                cs->depth++;
+            }
+            continue;
+        }
+        if (it.type == ITEM_CSG_END) {
+            if (HAS_CSG) {
+                cs->depth--;
+                int s0 = cs->depth < CSG_DEPTH ? cs->seg[cs->depth] : 0;
+                // sort the operand lists together (stable by t == by (t, key)), src/csg.rs:70-71
+                for (int a = s0 + 1; a < cs->n; ++a) {
+                    double ta = cs->t[a], ua = cs->u[a], va = cs->v[a];
+                    int ka = cs->key[a];
+                    if (ta != ta) cs->flags |= RT_FLAG_NAN_T;
+                    int b = a - 1;
+                    while (b >= s0 && key_less(ta, ka & ~(1 << 30), cs->t[b], cs->key[b] & ~(1 << 30))) {
+                        cs->t[b + 1] = cs->t[b]; cs->u[b + 1] = cs->u[b]; cs->v[b + 1] = cs->v[b]; cs->key[b + 1] = cs->key[b];
+                        --b;
+                    }
+                    cs->t[b + 1] = ta; cs->u[b + 1] = ua; cs->v[b + 1] = va; cs->key[b + 1] = ka;
+                }
+                // filter_intersections, src/csg.rs:106-126
+                bool inl = false, inr = false;
+                int wr = s0;
+                for (int a = s0; a < cs->n; ++a) {
+                    int node = (cs->key[a] & ~(1 << 30)) >> 2;
+                    bool left_hit = node >= it.a && node < it.b;  // Shape::includes by subtree membership
+                    if (csg_allowed(it.op, left_hit, inl, inr)) {
+                        cs->t[wr] = cs->t[a]; cs->u[wr] = cs->u[a]; cs->v[wr] = cs->v[a]; cs->key[wr] = cs->key[a];
+                        ++wr;
+                    }
+                    if (left_hit) inl = !inl; else inr = !inr;
+                }
+                cs->n = wr;
+                if (cs->depth == 0) {  // outermost CSG done: its survivors join the world list
+                    for (int a = 0; a < cs->n; ++a)
+                        sink.emit(cs->t[a], cs->key[a] & ~(1 << 30), cs->u[a], cs->v[a], (cs->key[a] >> 30) & 1);
+                    cs->n = 0;
+                }
+            }
+            continue;
+        }
+        V3 o = ro, d = rd;
+        apply_chain(S, it.chain, o, d, w.xforms);
+        if (it.type == ITEM_GATE) {  // Group::intersect gate, src/group.rs:52-53
+            bump<COUNT>(w.gate);
+            double tmin, tmax;
+            if (!slabs(o, d, S.group_box + (size_t)it.a * 6, tmin, tmax)) i = it.skip;
+            continue;
+        }
+        if (it.type == ITEM_MESH) {
+            bool full_line = HAS_CSG && cs->depth > 0;  // a CSG filter needs its operands' hits behind the origin too
+            bvh_traverse<COUNT>(S, it.a, o, d, sink, full_line, stack, w, out);
+            continue;
+        }
+        // ITEM_LEAF
+        const int node = it.node;
+        const int kind = S.node_kind[node];
+        auto leaf_out = [&](double t, int k, double u, double v, int uv) { out(t, node * 4 + k, u, v, uv); };
+        switch (kind) {
+            case RT_SPHERE: bump<COUNT>(w.prim[0]); isect_sphere(o, d, leaf_out); break;
+            case RT_PLANE: bump<COUNT>(w.prim[1]); isect_plane(o, d, leaf_out); break;
+            case RT_CUBE: bump<COUNT>(w.prim[2]); isect_cube(o, d, leaf_out); break;
+            case RT_CYLINDER:
+            case RT_CONE: {
+                int p = S.node_param[node];
+                double mn = S.conic[2 * p], mx = S.conic[2 * p + 1];
+                bool closed = S.conic_closed[p] != 0;
+                if (kind == RT_CYLINDER) { bump<COUNT>(w.prim[3]); isect_cylinder(o, d, mn, mx, closed, leaf_out); }
+                else { bump<COUNT>(w.prim[4]); isect_cone(o, d, mn, mx, closed, leaf_out); }
+                break;
+            }
+            default: {  // RT_TRIANGLE / RT_SMOOTH_TRIANGLE outside a mesh
+                const double* __restrict__ t = S.tri + (size_t)S.node_param[node] * 12;
+                isect_triangle<COUNT>(o, d, mk(t[0], t[1], t[2]), mk(t[3], t[4], t[5]), mk(t[6], t[7], t[8]),
+                                      kind == RT_SMOOTH_TRIANGLE, w, leaf_out);
+                break;
+            }
+        }
+    }
+    if (HAS_CSG) sink.flags |= cs->flags;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wave-level helpers.
+
+__device__ __forceinline__ void flush_work(const Work& w, unsigned long long* __restrict__ counters) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(&w);
+    constexpr int N = sizeof(Work) / sizeof(unsigned);
+    for (int k = 0; k < N; ++k) {
+        unsigned v = p[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counters + CNT_W_XFORMS + k, (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel: ray generation == Camera::ray_for_pixel (src/camera.rs:37-60) for this shard's 8x8 tiles.
+
+__device__ __forceinline__ bool slot_to_pixel(const CameraParams& c, long long slot, int& px, int& py) {
+    long long local_tile = slot >> 6;
+    int lane = int(slot & 63);
+    long long tile = local_tile * c.n_ranks + c.rank;
+    int ty = int(tile / c.tiles_x), tx = int(tile - (long long)ty * c.tiles_x);
+    px = tx * 8 + (lane & 7);
+    py = ty * 8 + (lane >> 3);
+    return ty < c.tiles_y && px < c.hsize - 1 && py < c.vsize - 1;  // F1: last row / column never rendered
+}
+
+__device__ __forceinline__ void ray_for_pixel(const CameraParams& c, int px, int py, V3& origin, V3& direction) {
+    double x_offset = ((double)px + 0.5) * c.pixel_size;
+    double y_offset = ((double)py + 0.5) * c.pixel_size;
+    double world_x = c.half_width - x_offset;
+    double world_y = c.half_height - y_offset;
+    V3 pixel = xf_point(c.inv, mk(world_x, world_y, -1.));
+    origin = xf_point(c.inv, mk(0., 0., 0.));
+    direction = normalize(vsub(pixel, origin));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_raygen(CameraParams c, Level L, long long n_slots) {
+    long long slot = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= n_slots) return;
+    int px, py;
+    if (!slot_to_pixel(c, slot, px, py)) {
+        L.ox[slot] = NAN;  // padding slot: no ray
+        return;
+    }
+    V3 origin, direction;
+    ray_for_pixel(c, px, py, origin, direction);
+    L.ox[slot] = origin.x; L.oy[slot] = origin.y; L.oz[slot] = origin.z;
+    L.dx[slot] = direction.x; L.dy[slot] = direction.y; L.dz[slot] = direction.z;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long long n, const int32_t* __restrict__ px,
+                                                           const int32_t* __restrict__ py, double* o_out, double* d_out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    V3 origin, direction;
+    ray_for_pixel(c, px[i], py[i], origin, direction);
+    o_out[3 * i] = origin.x; o_out[3 * i + 1] = origin.y; o_out[3 * i + 2] = origin.z;
+    d_out[3 * i] = direction.x; d_out[3 * i + 1] = direction.y; d_out[3 * i + 2] = direction.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel: closest hit for one level == intersect_world + Intersection::hit (+ which u,v normal_at will see).
+
+template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, Level L, long long n, unsigned long long* counters) {
+    __shared__ int stack[BVH_STACK * BLOCK];
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    Work w = {};
+    if (i < n) {
+        V3 o = mk(L.ox[i], L.oy[i], L.oz[i]);
+        if (o.x == o.x) {
+            V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            ClosestSink<NEED_FIRST> sink;
+            sink.init(INFINITY);
+            traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w);
+            double u = sink.bu, v = sink.bv;
+            unsigned flags = sink.flags;
+            if (NEED_FIRST && sink.best_key >= 0 && S.node_kind[sink.best_key >> 2] == RT_SMOOTH_TRIANGLE) {
+                if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+                else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+            }
+            L.ht[i] = sink.best_t; L.hu[i] = u; L.hv[i] = v;
+            L.hkey[i] = sink.best_key;
+            L.flags[i] = (uint8_t)flags;
+        } else {
+            L.hkey[i] = -1;
+            L.flags[i] = 0;
+        }
+    }
+    if (COUNT) flush_work(w, counters);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shading: prepare_computations, is_shadowed, lighting, ray spawn.
+
+// Shape::normal_at (src/shape.rs:92-108): world_to_object down the registry chain, local normal, normal_to_world up.
+__device__ __forceinline__ V3 world_to_object(const DScene& S, int node, V3 p) {  // src/shape.rs:394-404
+    const int* __restrict__ c = S.chain_pool + S.node_nchain[node];
+    for (int k = c[0]; k >= 1; --k)  // outermost ancestor first
+        if (c[k] != 0) p = xf_point(S.xf + (size_t)c[k] * 12, p);
+    return p;
+}
+__device__ __forceinline__ V3 normal_to_world(const DScene& S, int node, V3 n) {  // src/shape.rs:406-420
+    const int* __restrict__ c = S.chain_pool + S.node_nchain[node];
+    for (int k = 1; k <= c[0]; ++k) {
+        if (c[k] != 0) n = xf_normal(S.xf + (size_t)c[k] * 12, n);
+        n = normalize(n);  // every level normalises, identity or not
+    }
+    return n;
+}
+
+__device__ __forceinline__ V3 local_normal_at(const DScene& S, int node, int kind, V3 p, double hu, double hv) {
+    switch (kind) {
+        case RT_SPHERE: return p;               // point - ORIGIN, src/sphere.rs:65-67
+        case RT_PLANE: return mk(0., 1., 0.);   // src/plane.rs:53-56
+        case RT_CUBE: {                         // src/cube.rs:81-92
+            double maxc = max3nan(fabs(p.x), fabs(p.y), fabs(p.z));
+            if (near_eq(maxc, fabs(p.x))) return mk(p.x, 0., 0.);
+            else if (near_eq(maxc, fabs(p.y))) return mk(0., p.y, 0.);
+            else return mk(0., 0., p.z);
+        }
+        case RT_CYLINDER: {  // src/cylinder.rs:113-127
+            int q = S.node_param[node];
+            double minimum = S.conic[2 * q], maximum = S.conic[2 * q + 1];
+            double distance = p.x * p.x + p.z * p.z;
+            if (distance < 1. && (p.y > maximum - EPS || near_eq(p.y, maximum - EPS))) return mk(0., 1., 0.);
+            else if (distance < 1. && (p.y < minimum + EPS || near_eq(p.y, minimum + EPS))) return mk(0., -1., 0.);
+            else return mk(p.x, 0., p.z);
+        }
+        case RT_CONE: {  // src/cone.rs:119-135
+            int q = S.node_param[node];
+            double minimum = S.conic[2 * q], maximum = S.conic[2 * q + 1];
+            double distance = p.x * p.x + p.z * p.z;
+            if (distance < maximum * maximum && (p.y > maximum - EPS || near_eq(p.y, maximum - EPS))) return mk(0., 1., 0.);
+            else if (distance < minimum * minimum && (p.y < minimum + EPS || near_eq(p.y, minimum + EPS))) return mk(0., -1., 0.);
+            else {
+                double y = sqrt(distance);
+                return mk(p.x, p.y > 0. ? -y : y, p.z);
+            }
+        }
+        case RT_TRIANGLE: {  // src/triangle.rs:89-91
+            const double* __restrict__ t = S.tri + (size_t)S.node_param[node] * 12;
+            return mk(t[9], t[10], t[11]);
+        }
+        default: {  // RT_SMOOTH_TRIANGLE, src/smooth_triangle.rs:98-104
+            const double* __restrict__ s = S.smooth + (size_t)S.tri_smooth[S.node_param[node]] * 9;
+            V3 n1 = mk(s[0], s[1], s[2]), n2 = mk(s[3], s[4], s[5]), n3 = mk(s[6], s[7], s[8]);
+            return vadd(vadd(vmul(n2, hu), vmul(n3, hv)), vmul(n1, (1. - hu - hv)));
+        }
+    }
+}
+
+__device__ __forceinline__ int as_i32(double x) {  // Rust `as i32`: saturating, NaN -> 0
+    if (x != x) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return (-2147483647 - 1);
+    return (int)x;
+}
+
+// Pattern::pattern_at_shape (src/pattern.rs:23-35) and the six pattern_at bodies
+__device__ __forceinline__ V3 pattern_at_shape(const DScene& S, int pat, int node, V3 world_point) {
+    V3 object_point = world_to_object(S, node, world_point);
+    V3 p = xf_point(S.pat_inv + (size_t)pat * 12, object_point);
+    const double* __restrict__ ab = S.pat_ab + (size_t)pat * 6;
+    V3 a = mk(ab[0], ab[1], ab[2]), b = mk(ab[3], ab[4], ab[5]);
+    switch (S.pat_kind[pat]) {
+        case RT_PAT_STRIPED: return as_i32(floor(p.x)) % 2 == 0 ? a : b;
+        case RT_PAT_GRADIENT: {
+            V3 distance = vsub(b, a);
+            double fraction = p.x - floor(p.x);
+            return vadd(a, vmul(distance, fraction));
+        }
+        case RT_PAT_RING: return as_i32(floor(sqrt(p.x * p.x + p.z * p.z))) % 2 == 0 ? a : b;
+        case RT_PAT_CHECKERED: return as_i32(floor(p.x) + floor(p.y) + floor(p.z)) % 2 == 0 ? a : b;
+        case RT_PAT_RING_GRADIENT: {
+            V3 distance = vsub(b, a);
+            double c = sqrt(p.x * p.x + p.z * p.z);
+            double fraction = c - floor(c);
+            return vadd(a, vmul(distance, fraction));
+        }
+        default: return p;  // TestPattern
+    }
+}
+
+// Material::lighting (src/material.rs:97-129); colours ride in V3
+__device__ __forceinline__ V3 lighting(const DScene& S, const double* __restrict__ m, int pat, int node, int light, V3 point,
+                                       V3 eye_vector, V3 normal_vector, bool in_shadow) {
+    V3 real_color = pat >= 0 ? pattern_at_shape(S, pat, node, point) : mk(m[RT_MAT_R], m[RT_MAT_G], m[RT_MAT_B]);
+    const double* __restrict__ l = S.light + (size_t)light * 6;
+    V3 light_position = mk(l[0], l[1], l[2]), intensity = mk(l[3], l[4], l[5]);
+    V3 effective_color = vhad(real_color, intensity);
+    V3 light_vector = normalize(vsub(light_position, point));
+    V3 ambient = vmul(effective_color, m[RT_MAT_AMBIENT]);
+    double light_dot_normal = dot(light_vector, normal_vector);
+    V3 diffuse, specular;
+    if (light_dot_normal < 0.) {
+        diffuse = mk(0., 0., 0.);
+        specular = mk(0., 0., 0.);
+    } else {
+        diffuse = vmul(vmul(effective_color, m[RT_MAT_DIFFUSE]), light_dot_normal);
+        V3 reflect_vector = reflect(vneg(light_vector), normal_vector);
+        double reflect_dot_eye = dot(reflect_vector, eye_vector);
+        if (near_eq(0., reflect_dot_eye) || reflect_dot_eye < 0.) {
+            specular = mk(0., 0., 0.);
+        } else {
+            double factor = pow(reflect_dot_eye, m[RT_MAT_SHININESS]);
+            specular = vmul(vmul(intensity, m[RT_MAT_SPECULAR]), factor);
+        }
+    }
+    if (in_shadow) return ambient;
+    return vadd(vadd(ambient, diffuse), specular);
+}
+
+// World::is_shadowed for one light (src/world.rs:92-107): NEAREST hit only, then `t < distance && casts_shadow` (F8)
+template <bool HAS_CSG, bool COUNT>
+__device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light, int* __restrict__ stack, Work& w,
+                                            unsigned& flags) {
+    const double* __restrict__ l = S.light + (size_t)light * 6;
+    V3 vector = vsub(mk(l[0], l[1], l[2]), point);
+    double distance = magnitude(vector);
+    V3 direction = normalize(vector);
+    ClosestSink<false> sink;
+    // hits at t >= distance cannot shadow and cannot displace a nearer hit: bound the search there
+    sink.init(distance);
+    traverse<HAS_CSG, COUNT>(S, point, direction, sink, stack, w);
+    flags |= sink.flags;
+    if (sink.best_key < 0) return false;
+    return sink.best_t < distance && S.node_casts_shadow[sink.best_key >> 2] != 0;
+}
+
+// The n1/n2 walk of prepare_computations (src/intersection.rs:54-80) over the sorted list up to the hit.
+template <bool HAS_CSG, bool COUNT>
+__device__ __noinline__ void container_walk(const DScene& S, V3 o, V3 d, double hit_t, int hit_node, int* __restrict__ stack,
+                                            Work& w, double& n1_out, double& n2_out, unsigned& flags) {
+    double lt[LIST_CAP];
+    int lk[LIST_CAP];
+    ListSink sink;
+    sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
+    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w);
+    flags |= sink.flags;
+    int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
+    sort_list(lt, lk, n);
+    int containers[CONTAINER_CAP];
+    int nc = 0;
+    double n1 = 0., n2 = 0.;
+    const int hit_cls = S.node_eq_class[hit_node];
+    for (int i = 0; i < n; ++i) {
+        int node = lk[i] >> 2;
+        int cls = S.node_eq_class[node];
+        bool is_self = near_eq(lt[i], hit_t) && cls >= 0 && cls == hit_cls;  // Intersection::eq (F6, F14)
+        if (is_self) n1 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        int found = -1;
+        for (int k = 0; k < nc; ++k) {
+            int ck = S.node_eq_class[containers[k]];
+            if (ck >= 0 && ck == cls) { found = k; break; }
+        }
+        if (found >= 0) {
+            for (int k = found; k + 1 < nc; ++k) containers[k] = containers[k + 1];
+            --nc;
+        } else if (nc < CONTAINER_CAP) {
+            containers[nc++] = node;
+        } else {
+            flags |= RT_FLAG_LIST_OVERFLOW;
+        }
+        if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+    }
+    n1_out = n1;
+    n2_out = n2;
+}
+
+__device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, double n1, double n2) {  // src/intersection.rs:97-115
+    double cosv = dot(eye_vector, normal_vector);
+    if (n1 > n2) {
+        double n = n1 / n2;
+        double sin2_t = (n * n) * (1. - cosv * cosv);
+        if (sin2_t > 1.) return 1.;
+        double cos_t = sqrt(1. - sin2_t);
+        cosv = cos_t;
+    }
+    double q = (n1 - n2) / (n1 + n2);
+    double r0 = q * q;
+    double x = 1. - cosv;
+    return r0 + (1. - r0) * (x * ((x * x) * (x * x)));
+}
+
+// Kernel: shade one level.  `remaining` is the value color_at was called with at this level.
+template <bool HAS_CSG, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n, int remaining, long long next_cap,
+                                                  unsigned long long* counters) {
+    __shared__ int stack[BVH_STACK * BLOCK];
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    Work w = {};
+    bool want_refl = false, want_refr = false;
+    V3 refl_o = mk(0, 0, 0), refl_d = mk(0, 0, 0), refr_o = mk(0, 0, 0), refr_d = mk(0, 0, 0);
+    bool shaded = false, walked = false;
+    if (i < n) {
+        int key = L.hkey[i];
+        L.child_refl[i] = -1;
+        L.child_refr[i] = -1;
+        if (key >= 0) {
+            shaded = true;
+            unsigned flags = L.flags[i];
+            const int node = key >> 2;
+            const int kind = S.node_kind[node];
+            V3 o = mk(L.ox[i], L.oy[i], L.oz[i]), d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            const double t = L.ht[i];
+            // ---- prepare_computations, src/intersection.rs:38-53
+            V3 point = vadd(o, vmul(d, t));  // Ray::position
+            V3 local_point = world_to_object(S, node, point);
+            V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, L.hu[i], L.hv[i]));
+            V3 eye_vector = vneg(d);
+            if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
+            V3 over_point = vadd(point, vmul(normal_vector, EPS));
+            V3 under_point = vsub(point, vmul(normal_vector, EPS));
+            V3 reflect_vector = reflect(d, normal_vector);
+
+            const int mi = S.node_material[node];
+            const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
+            const int pat = S.mat_pattern[mi];
+            const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
+
+            // n1/n2 are read only by refracted_color and schlick, both behind a transparency test
+            double n1 = 0., n2 = 0.;
+            if (!near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.)) {
+                walked = true;
+                container_walk<HAS_CSG, COUNT>(S, o, d, t, node, stack, w, n1, n2, flags);
+            }
+
+            // ---- shade_hit, src/world.rs:57-66
+            V3 surface = mk(0., 0., 0.);
+            for (int l = 0; l < S.n_lights; ++l) {
+                bool shadow = is_shadowed<HAS_CSG, COUNT>(S, over_point, l, stack, w, flags);
+                surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector, shadow));
+            }
+            // ---- reflected_color, src/world.rs:109-118
+            if (!(near_eq(reflective, 0.) || remaining <= 0)) {
+                want_refl = true;
+                refl_o = over_point;
+                refl_d = reflect_vector;
+            }
+            // ---- refracted_color, src/world.rs:120-137
+            if (!(near_eq(transparency, 0.) || remaining <= 0)) {
+                double n_ratio = n1 / n2;
+                double cos_i = dot(eye_vector, normal_vector);
+                double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                if (!(sin2_t > 1.)) {
+                    double cos_t = sqrt(1. - sin2_t);
+                    refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
+                    refr_o = under_point;
+                    want_refr = true;
+                }
+            }
+            int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
+            L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
+            L.k_refl[i] = reflective;
+            L.k_transp[i] = transparency;
+            L.k_schlick[i] = mode ? schlick(eye_vector, normal_vector, n1, n2) : 0.;
+            L.mode[i] = mode;
+            L.flags[i] = (uint8_t)flags;
+        }
+    }
+    // ---- spawn: one atomic per wavefront, slots handed out by ballot + mbcnt prefix
+    unsigned long long b_refl = __ballot(want_refl), b_refr = __ballot(want_refr);
+    unsigned long long b_shaded = __ballot(shaded), b_walk = __ballot(walked);
+    int c_refl = __popcll(b_refl), c_refr = __popcll(b_refr);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0) {
+        if (c_refl + c_refr) base = atomicAdd(counters + CNT_NEXT, (unsigned long long)(c_refl + c_refr));
+        if (c_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)c_refl);
+        if (c_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)c_refr);
+        if (b_shaded) atomicAdd(counters + CNT_SHADED, (unsigned long long)__popcll(b_shaded));
+        if (b_walk) atomicAdd(counters + CNT_CONTAINER, (unsigned long long)__popcll(b_walk));
+    }
+    base = __shfl(base, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (want_refl) {
+        long long s = (long long)base + __popcll(b_refl & below);
+        if (s < next_cap) {
+            N.ox[s] = refl_o.x; N.oy[s] = refl_o.y; N.oz[s] = refl_o.z;
+            N.dx[s] = refl_d.x; N.dy[s] = refl_d.y; N.dz[s] = refl_d.z;
+            L.child_refl[i] = (int)s;
+        }
+    }
+    if (want_refr) {
+        long long s = (long long)base + c_refl + __popcll(b_refr & below);
+        if (s < next_cap) {
+            N.ox[s] = refr_o.x; N.oy[s] = refr_o.y; N.oz[s] = refr_o.z;
+            N.dx[s] = refr_d.x; N.dy[s] = refr_d.y; N.dz[s] = refr_d.z;
+            L.child_refr[i] = (int)s;
+        }
+    }
+    if (COUNT) flush_work(w, counters);
+}
+
+// Kernel: bottom-up resolve of one level == the tail of shade_hit (src/world.rs:68-78) + color_at's miss case.
+__global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n, int has_next) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (L.hkey[i] < 0) {  // miss -> BLACK
+        L.cr[i] = 0.; L.cg[i] = 0.; L.cb[i] = 0.;
+        return;
+    }
+    V3 surface = mk(L.sr[i], L.sg[i], L.sb[i]);
+    V3 reflected = mk(0., 0., 0.), refracted = mk(0., 0., 0.);
+    unsigned flags = L.flags[i];
+    int c0 = L.child_refl[i], c1 = L.child_refr[i];
+    if (has_next && c0 >= 0) {
+        reflected = vmul(mk(N.cr[c0], N.cg[c0], N.cb[c0]), L.k_refl[i]);
+        flags |= N.flags[c0];
+    }
+    if (has_next && c1 >= 0) {
+        refracted = vmul(mk(N.cr[c1], N.cg[c1], N.cb[c1]), L.k_transp[i]);
+        flags |= N.flags[c1];
+    }
+    V3 out;
+    if (L.mode[i]) {
+        double reflectance = L.k_schlick[i];
+        out = vadd(vadd(surface, vmul(reflected, reflectance)), vmul(refracted, (1. - reflectance)));
+    } else {
+        out = vadd(vadd(surface, reflected), refracted);
+    }
+    L.cr[i] = out.x; L.cg[i] = out.y; L.cb[i] = out.z;
+    L.flags[i] = (uint8_t)flags;
+}
+
+// Kernel: level-0 colours -> caller's buffers, interleaved RGB.  frame == 0: shard-local order; frame == 1:
+// scatter into the full row-major frame (Canvas layout, src/canvas.rs:25-27).
+__global__ __launch_bounds__(BLOCK) void k_output(DScene S, Level L, long long n, double* rgb, int32_t* hit_id, uint8_t* flags) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    rgb[3 * i] = L.cr[i]; rgb[3 * i + 1] = L.cg[i]; rgb[3 * i + 2] = L.cb[i];
+    if (hit_id) {
+        int key = L.hkey[i];
+        hit_id[i] = key >= 0 ? S.node_object_id[key >> 2] : 0;
+    }
+    if (flags) flags[i] = L.flags[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_slots, const double* __restrict__ rgb_in,
+                                                    const int32_t* __restrict__ id_in, const uint8_t* __restrict__ fl_in,
+                                                    double* rgb_out, int32_t* id_out, uint8_t* fl_out) {
+    long long slot = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= n_slots) return;
+    int px, py;
+    if (!slot_to_pixel(c, slot, px, py)) return;
+    long long p = (long long)py * c.hsize + px;
+    rgb_out[3 * p] = rgb_in[3 * slot]; rgb_out[3 * p + 1] = rgb_in[3 * slot + 1]; rgb_out[3 * p + 2] = rgb_in[3 * slot + 2];
+    if (id_out && id_in) id_out[p] = id_in[slot];
+    if (fl_out && fl_in) fl_out[p] = fl_in[slot];
+}
+
+// Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
+template <bool HAS_CSG>
+__global__ __launch_bounds__(BLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
+                                                const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
+                                                int32_t* id_out) {
+    __shared__ int stack[BVH_STACK * BLOCK];
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double lt[LIST_CAP];
+    int lk[LIST_CAP];
+    ListSink sink;
+    sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = INFINITY; sink.flags = 0;
+    Work w = {};
+    traverse<HAS_CSG, false>(S, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+                             mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), sink, stack, w);
+    int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
+    sort_list(lt, lk, m);
+    count[i] = sink.n;
+    for (int k = 0; k < m && k < max_hits; ++k) {
+        t_out[i * max_hits + k] = lt[k];
+        id_out[i * max_hits + k] = S.node_object_id[lk[k] >> 2];
+    }
+}
+
+// Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
+template <bool HAS_CSG>
+__global__ __launch_bounds__(BLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
+    __shared__ int stack[BVH_STACK * BLOCK];
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Work w = {};
+    unsigned flags = 0;
+    V3 p = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    for (int l = 0; l < S.n_lights; ++l) out[i * S.n_lights + l] = is_shadowed<HAS_CSG, false>(S, p, l, stack, w, flags) ? 1 : 0;
+}
+
+// Kernel: load caller rays into level 0 (rt_color_at).
+__global__ __launch_bounds__(BLOCK) void k_load_rays(Level L, long long n, const double* __restrict__ origins,
+                                                     const double* __restrict__ dirs) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    L.ox[i] = origins[3 * i]; L.oy[i] = origins[3 * i + 1]; L.oz[i] = origins[3 * i + 2];
+    L.dx[i] = dirs[3 * i]; L.dy[i] = dirs[3 * i + 1]; L.dz[i] = dirs[3 * i + 2];
+}
+
+}  // namespace rt

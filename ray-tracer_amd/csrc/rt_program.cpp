@@ -1,0 +1,405 @@
+// rt_program.cpp — descriptor validation, traversal-program compilation and BVH build (host side of
+// rt_scene_create).  See rt_program.h for what the program is and why it cannot change results.
+#include "rt_program.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <unordered_set>
+
+namespace rt {
+namespace {
+
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+struct Compiler {
+    const rt_scene_desc& d;
+    Program& p;
+    std::map<std::vector<int32_t>, int32_t> chain_index;
+    std::map<std::pair<int32_t, int32_t>, int32_t> nchain_index;
+
+    Compiler(const rt_scene_desc& desc, Program& prog) : d(desc), p(prog) {}
+
+    int32_t chain_offset(const std::vector<int32_t>& chain) {
+        auto it = chain_index.find(chain);
+        if (it != chain_index.end()) return it->second;
+        int32_t off = int32_t(p.chain_pool.size());
+        p.chain_pool.push_back(int32_t(chain.size()));
+        for (int32_t x : chain) p.chain_pool.push_back(x);
+        chain_index.emplace(chain, off);
+        p.max_chain = std::max(p.max_chain, int32_t(chain.size()));
+        return off;
+    }
+
+    int32_t nchain_offset(int32_t node) {
+        std::pair<int32_t, int32_t> key{d.node_xform[node], d.node_ancestor[node]};
+        auto it = nchain_index.find(key);
+        if (it != nchain_index.end()) return it->second;
+        std::vector<int32_t> c{d.node_xform[node]};
+        for (int32_t a = d.node_ancestor[node]; a >= 0; a = d.ancestor_parent[a]) c.push_back(d.ancestor_xform[a]);
+        int32_t off = int32_t(p.chain_pool.size());
+        p.chain_pool.push_back(int32_t(c.size()));
+        for (int32_t x : c) p.chain_pool.push_back(x);
+        nchain_index.emplace(key, off);
+        p.max_chain = std::max(p.max_chain, int32_t(c.size()));
+        return off;
+    }
+
+    static bool is_leaf_kind(int32_t k) { return k >= RT_SPHERE && k <= RT_SMOOTH_TRIANGLE; }
+    static bool is_tri_kind(int32_t k) { return k == RT_TRIANGLE || k == RT_SMOOTH_TRIANGLE; }
+
+    // ---- BVH -------------------------------------------------------------------------------------------
+    struct TriRef {
+        int32_t node;
+        double lo[3], hi[3], c[3];
+    };
+    struct Box {
+        double lo[3], hi[3];
+        void reset() {
+            for (int k = 0; k < 3; ++k) { lo[k] = INF; hi[k] = -INF; }
+        }
+        void add(const double* l, const double* h) {
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+        }
+    };
+    double pad = 0.;
+    int depth_seen = 0;
+
+    static constexpr int32_t EMPTY = std::numeric_limits<int32_t>::min();
+
+    int32_t emit_leaf(std::vector<TriRef>& refs, size_t lo, size_t hi) {
+        int32_t first = int32_t(p.mesh_tris.size());
+        for (size_t i = lo; i < hi; ++i) {
+            int32_t node = refs[i].node;
+            int32_t t = d.node_param[node];
+            MeshTri mt;
+            for (int k = 0; k < 3; ++k) {
+                mt.p1[k] = d.tri_p1[3 * t + k];
+                mt.e1[k] = d.tri_e1[3 * t + k];
+                mt.e2[k] = d.tri_e2[3 * t + k];
+            }
+            mt.node = node;
+            mt.smooth = d.node_kind[node] == RT_SMOOTH_TRIANGLE ? 1 : 0;
+            p.mesh_tris.push_back(mt);
+        }
+        return ~((first << 4) | int32_t(hi - lo - 1));
+    }
+
+    // Builds [lo,hi) and returns the child reference plus its (padded) box.
+    int32_t build(std::vector<TriRef>& refs, size_t lo, size_t hi, Box& box, int depth) {
+        depth_seen = std::max(depth_seen, depth);
+        box.reset();
+        Box cb;
+        cb.reset();
+        for (size_t i = lo; i < hi; ++i) {
+            box.add(refs[i].lo, refs[i].hi);
+            cb.add(refs[i].c, refs[i].c);
+        }
+        for (int k = 0; k < 3; ++k) { box.lo[k] -= pad; box.hi[k] += pad; }
+        size_t n = hi - lo;
+        if (n <= size_t(BVH_LEAF_MAX)) return emit_leaf(refs, lo, hi);
+
+        // binned SAH on the longest centroid axis; falls back to an index median when it cannot separate
+        int axis = 0;
+        double ext = cb.hi[0] - cb.lo[0];
+        for (int k = 1; k < 3; ++k)
+            if (cb.hi[k] - cb.lo[k] > ext) { ext = cb.hi[k] - cb.lo[k]; axis = k; }
+        size_t mid = lo + n / 2;
+        bool split_done = false;
+        int lg = 0;
+        while ((size_t(1) << lg) < n) ++lg;
+        // SAH may unbalance the tree; allow it only while a median-split subtree would still fit the device stack
+        if (ext > 0. && depth + lg + 2 < BVH_STACK) {
+            constexpr int NB = 16;
+            Box bb[NB];
+            size_t cnt[NB] = {0};
+            for (auto& b : bb) b.reset();
+            double scale = double(NB) / ext;
+            auto bin_of = [&](const TriRef& r) {
+                int b = int((r.c[axis] - cb.lo[axis]) * scale);
+                return std::min(std::max(b, 0), NB - 1);
+            };
+            for (size_t i = lo; i < hi; ++i) {
+                int b = bin_of(refs[i]);
+                bb[b].add(refs[i].lo, refs[i].hi);
+                cnt[b]++;
+            }
+            auto area = [](const Box& b) {
+                double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+                if (!(dx >= 0.)) return 0.;
+                return dx * dy + dy * dz + dz * dx;
+            };
+            double right_area[NB];
+            size_t right_cnt[NB];
+            Box acc;
+            acc.reset();
+            size_t c = 0;
+            for (int b = NB - 1; b > 0; --b) {
+                if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
+                c += cnt[b];
+                right_area[b] = area(acc);
+                right_cnt[b] = c;
+            }
+            acc.reset();
+            c = 0;
+            double best = INF;
+            int best_b = -1;
+            for (int b = 0; b + 1 < NB; ++b) {
+                if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
+                c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                double cost = area(acc) * double(c) + right_area[b + 1] * double(right_cnt[b + 1]);
+                if (cost < best) { best = cost; best_b = b; }
+            }
+            if (best_b >= 0) {
+                auto it = std::partition(refs.begin() + long(lo), refs.begin() + long(hi),
+                                         [&](const TriRef& r) { return bin_of(r) <= best_b; });
+                size_t m = size_t(it - refs.begin());
+                if (m > lo && m < hi) { mid = m; split_done = true; }
+            }
+        }
+        if (!split_done) {
+            if (ext > 0.)
+                std::nth_element(refs.begin() + long(lo), refs.begin() + long(mid), refs.begin() + long(hi),
+                                 [&](const TriRef& a, const TriRef& b) { return a.c[axis] < b.c[axis]; });
+            // ext == 0: all centroids coincide (e.g. repeated fan triangles, F3) — halve by index
+        }
+        int32_t me = int32_t(p.bvh.size());
+        p.bvh.emplace_back();
+        Box b0, b1;
+        int32_t c0 = build(refs, lo, mid, b0, depth + 1);
+        int32_t c1 = build(refs, mid, hi, b1, depth + 1);
+        BvhNode& nd = p.bvh[size_t(me)];
+        std::memset(&nd, 0, sizeof nd);
+        for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
+        nd.c0 = c0;
+        nd.c1 = c1;
+        return me;
+    }
+
+    int32_t build_mesh(const std::vector<int32_t>& tri_nodes) {
+        std::vector<TriRef> refs(tri_nodes.size());
+        double maxabs = 0.;
+        Box all;
+        all.reset();
+        for (size_t i = 0; i < tri_nodes.size(); ++i) {
+            TriRef& r = refs[i];
+            r.node = tri_nodes[i];
+            int32_t t = d.node_param[r.node];
+            for (int k = 0; k < 3; ++k) {
+                double a = d.tri_p1[3 * t + k], b = a + d.tri_e1[3 * t + k], c = a + d.tri_e2[3 * t + k];
+                r.lo[k] = std::min(a, std::min(b, c));
+                r.hi[k] = std::max(a, std::max(b, c));
+                r.c[k] = 0.5 * r.lo[k] + 0.5 * r.hi[k];
+                maxabs = std::max(maxabs, std::max(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
+            }
+            all.add(r.lo, r.hi);
+        }
+        // Conservative padding: the reference accepts u,v in [0,1] as COMPUTED (relative error ~1e-16) and our
+        // p2/p3 are re-derived from edges; 1e-7 of the mesh scale is nine orders of magnitude above both.
+        pad = 1e-7 * maxabs + 1e-300;
+        Box rb;
+        int32_t root = build(refs, 0, refs.size(), rb, 0);
+        if (root < 0) {  // the whole mesh is one leaf: wrap it in a node
+            int32_t me = int32_t(p.bvh.size());
+            p.bvh.emplace_back();
+            BvhNode& nd = p.bvh[size_t(me)];
+            std::memset(&nd, 0, sizeof nd);
+            for (int k = 0; k < 3; ++k) { nd.lo0[k] = rb.lo[k]; nd.hi0[k] = rb.hi[k]; nd.lo1[k] = INF; nd.hi1[k] = -INF; }
+            nd.c0 = root;
+            nd.c1 = EMPTY;
+            root = me;
+        }
+        p.bvh_max_depth = std::max(p.bvh_max_depth, depth_seen);
+        return root;
+    }
+
+    // ---- traversal program -----------------------------------------------------------------------------
+    void emit(int32_t node, std::vector<int32_t> chain) {
+        int32_t x = d.node_xform[node];
+        if (x != 0) chain.push_back(x);
+        int32_t kind = d.node_kind[node];
+        if (is_leaf_kind(kind)) {
+            Item it{};
+            it.type = ITEM_LEAF;
+            it.node = node;
+            it.chain = chain_offset(chain);
+            p.items.push_back(it);
+            return;
+        }
+        if (kind == RT_GROUP) {
+            const double* box = d.group_box + size_t(d.node_param[node]) * 6;
+            bool infinite = true, empty = true;
+            for (int k = 0; k < 3; ++k) {
+                infinite = infinite && box[k] == -INF && box[3 + k] == INF;
+                empty = empty && box[k] == INF && box[3 + k] == -INF;
+            }
+            int32_t gate = -1;
+            if (!infinite && !empty) {  // both of those pass for every ray ("Group gate")
+                Item it{};
+                it.type = ITEM_GATE;
+                it.node = node;
+                it.chain = chain_offset(chain);
+                it.a = d.node_param[node];
+                gate = int32_t(p.items.size());
+                p.items.push_back(it);
+            }
+            std::vector<int32_t> tris;
+            for (int32_t c = node + 1; c < d.node_subtree_end[node]; c = d.node_subtree_end[c])
+                if (is_tri_kind(d.node_kind[c]) && d.node_xform[c] == 0) tris.push_back(c);
+            bool mesh = tris.size() >= size_t(MESH_MIN_TRIANGLES);
+            if (mesh) {
+                Item it{};
+                it.type = ITEM_MESH;
+                it.node = node;
+                it.chain = chain_offset(chain);
+                it.a = build_mesh(tris);
+                p.items.push_back(it);
+            }
+            for (int32_t c = node + 1; c < d.node_subtree_end[node]; c = d.node_subtree_end[c]) {
+                if (mesh && is_tri_kind(d.node_kind[c]) && d.node_xform[c] == 0) continue;
+                emit(c, chain);
+            }
+            if (gate >= 0) p.items[size_t(gate)].skip = int32_t(p.items.size());
+            return;
+        }
+        // CSG
+        int32_t left = node + 1, right = d.node_subtree_end[left];
+        Item b{};
+        b.type = ITEM_CSG_BEGIN;
+        b.node = node;
+        p.items.push_back(b);
+        emit(left, chain);
+        emit(right, chain);
+        Item e{};
+        e.type = ITEM_CSG_END;
+        e.node = node;
+        e.a = left;
+        e.b = d.node_subtree_end[left];
+        e.op = d.csg_op[d.node_param[node]];
+        p.items.push_back(e);
+        p.has_csg = true;
+    }
+};
+
+bool affine_row(const double* m16) {
+    return m16[12] == 0. && m16[13] == 0. && m16[14] == 0. && m16[15] == 1.;
+}
+
+#define FAIL(code, ...)                                  \
+    do {                                                 \
+        char buf_[512];                                  \
+        std::snprintf(buf_, sizeof buf_, __VA_ARGS__);   \
+        err = buf_;                                      \
+        return code;                                     \
+    } while (0)
+
+int validate(const rt_scene_desc& d, std::string& err) {
+    if (d.abi_version != RT_ABI_VERSION) FAIL(RT_ERR_BAD_ARG, "abi_version %d, library speaks %d", d.abi_version, RT_ABI_VERSION);
+    if (d.n_nodes < 0 || d.n_xforms < 1 || d.n_ancestors < 0 || d.n_groups < 0 || d.n_csg < 0 || d.n_conics < 0 ||
+        d.n_triangles < 0 || d.n_smooth < 0 || d.n_materials < 0 || d.n_patterns < 0 || d.n_lights < 0)
+        FAIL(RT_ERR_BAD_ARG, "negative table size (n_xforms must be >= 1: xform 0 is the identity)");
+    if (d.n_nodes > (1 << 28)) FAIL(RT_ERR_UNSUPPORTED, "more than 2^28 nodes");
+    if (d.n_nodes && (!d.node_kind || !d.node_object_id || !d.node_parent || !d.node_subtree_end || !d.node_xform ||
+                      !d.node_ancestor || !d.node_material || !d.node_casts_shadow || !d.node_eq_class || !d.node_param))
+        FAIL(RT_ERR_BAD_ARG, "null node table");
+    if (!d.xform_inverse || !d.xform_inverse_transpose) FAIL(RT_ERR_BAD_ARG, "null xform table");
+    if ((d.n_ancestors && (!d.ancestor_xform || !d.ancestor_parent)) || (d.n_groups && !d.group_box) ||
+        (d.n_csg && !d.csg_op) || (d.n_conics && (!d.conic_minimum || !d.conic_maximum || !d.conic_closed)) ||
+        (d.n_triangles && (!d.tri_p1 || !d.tri_e1 || !d.tri_e2 || !d.tri_normal || !d.tri_smooth)) ||
+        (d.n_smooth && (!d.smooth_n1 || !d.smooth_n2 || !d.smooth_n3)) ||
+        (d.n_materials && (!d.material_params || !d.material_pattern)) ||
+        (d.n_patterns && (!d.pattern_kind || !d.pattern_a || !d.pattern_b || !d.pattern_inverse)) ||
+        (d.n_lights && (!d.light_position || !d.light_intensity)))
+        FAIL(RT_ERR_BAD_ARG, "null table with a non-zero count");
+    for (int i = 0; i < 16; ++i)
+        if (d.xform_inverse[i] != ((i % 5 == 0) ? 1. : 0.)) FAIL(RT_ERR_BAD_ARG, "xform 0 must be the exact identity");
+    for (int32_t x = 0; x < d.n_xforms; ++x)
+        if (!affine_row(d.xform_inverse + size_t(x) * 16))
+            FAIL(RT_ERR_UNSUPPORTED, "xform %d: inverse is not affine (last row must be 0,0,0,1)", x);
+    for (int32_t q = 0; q < d.n_patterns; ++q) {
+        if (!affine_row(d.pattern_inverse + size_t(q) * 16)) FAIL(RT_ERR_UNSUPPORTED, "pattern %d: inverse is not affine", q);
+        if (d.pattern_kind[q] < RT_PAT_STRIPED || d.pattern_kind[q] > RT_PAT_TEST) FAIL(RT_ERR_BAD_ARG, "pattern %d: bad kind", q);
+    }
+    for (int32_t a = 0; a < d.n_ancestors; ++a) {
+        if (d.ancestor_xform[a] < 0 || d.ancestor_xform[a] >= d.n_xforms) FAIL(RT_ERR_BAD_ARG, "ancestor %d: xform out of range", a);
+        int32_t up = d.ancestor_parent[a];
+        if (up < -1 || up >= d.n_ancestors) FAIL(RT_ERR_BAD_ARG, "ancestor %d: parent out of range", a);
+        int steps = 0;
+        for (int32_t c = a; c >= 0; c = d.ancestor_parent[c])
+            if (++steps > 64) FAIL(RT_ERR_UNSUPPORTED, "ancestor %d: parent chain deeper than 64 (or cyclic)", a);
+    }
+    for (int32_t m = 0; m < d.n_materials; ++m)
+        if (d.material_pattern[m] < -1 || d.material_pattern[m] >= d.n_patterns) FAIL(RT_ERR_BAD_ARG, "material %d: pattern out of range", m);
+    for (int32_t t = 0; t < d.n_triangles; ++t)
+        if (d.tri_smooth[t] < -1 || d.tri_smooth[t] >= d.n_smooth) FAIL(RT_ERR_BAD_ARG, "triangle %d: smooth index out of range", t);
+    for (int32_t n = 0; n < d.n_nodes; ++n) {
+        int32_t k = d.node_kind[n];
+        if (k < RT_SPHERE || k > RT_CSG) FAIL(RT_ERR_BAD_ARG, "node %d: bad kind %d", n, k);
+        if (d.node_xform[n] < 0 || d.node_xform[n] >= d.n_xforms) FAIL(RT_ERR_BAD_ARG, "node %d: xform out of range", n);
+        int32_t end = d.node_subtree_end[n];
+        if (end <= n || end > d.n_nodes) FAIL(RT_ERR_BAD_ARG, "node %d: bad subtree_end", n);
+        int32_t par = d.node_parent[n];
+        if (par < -1 || par >= n) FAIL(RT_ERR_BAD_ARG, "node %d: bad parent", n);
+        if (par >= 0 && end > d.node_subtree_end[par]) FAIL(RT_ERR_BAD_ARG, "node %d: subtree exceeds its parent's", n);
+        int32_t prm = d.node_param[n];
+        bool leaf = k <= RT_SMOOTH_TRIANGLE;
+        if (leaf) {
+            if (end != n + 1) FAIL(RT_ERR_BAD_ARG, "node %d: a primitive cannot have children", n);
+            if (d.node_material[n] < 0 || d.node_material[n] >= d.n_materials) FAIL(RT_ERR_BAD_ARG, "node %d: material out of range", n);
+            if (d.node_ancestor[n] < -1 || d.node_ancestor[n] >= d.n_ancestors) FAIL(RT_ERR_BAD_ARG, "node %d: ancestor out of range", n);
+        }
+        if ((k == RT_CYLINDER || k == RT_CONE) && (prm < 0 || prm >= d.n_conics)) FAIL(RT_ERR_BAD_ARG, "node %d: conic index out of range", n);
+        if ((k == RT_TRIANGLE || k == RT_SMOOTH_TRIANGLE)) {
+            if (prm < 0 || prm >= d.n_triangles) FAIL(RT_ERR_BAD_ARG, "node %d: triangle index out of range", n);
+            if ((k == RT_SMOOTH_TRIANGLE) != (d.tri_smooth[prm] >= 0)) FAIL(RT_ERR_BAD_ARG, "node %d: kind and tri_smooth disagree", n);
+        }
+        if (k == RT_GROUP && (prm < 0 || prm >= d.n_groups)) FAIL(RT_ERR_BAD_ARG, "node %d: group index out of range", n);
+        if (k == RT_CSG) {
+            if (prm < 0 || prm >= d.n_csg) FAIL(RT_ERR_BAD_ARG, "node %d: csg index out of range", n);
+            int32_t left = n + 1;
+            if (left >= end) FAIL(RT_ERR_BAD_ARG, "node %d: CSG without operands", n);
+            int32_t right = d.node_subtree_end[left];
+            if (right <= left || right >= end || d.node_subtree_end[right] != end) FAIL(RT_ERR_BAD_ARG, "node %d: CSG needs exactly two operands", n);
+            // Shape::includes compares ids (src/shape.rs:422-435): the device tests node ranges instead, which is
+            // the same thing unless one id sits in both operands.
+            std::unordered_set<int32_t> left_ids;
+            for (int32_t i = left; i < right; ++i)
+                if (d.node_kind[i] <= RT_SMOOTH_TRIANGLE) left_ids.insert(d.node_object_id[i]);
+            for (int32_t i = right; i < end; ++i)
+                if (d.node_kind[i] <= RT_SMOOTH_TRIANGLE && left_ids.count(d.node_object_id[i]))
+                    FAIL(RT_ERR_UNSUPPORTED, "node %d: object id %d appears in both CSG operands", n, d.node_object_id[i]);
+        }
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err) {
+    int rc = validate(d, err);
+    if (rc != RT_OK) return rc;
+    Compiler c(d, out);
+    // chain 0 = the empty chain
+    c.chain_offset({});
+    out.node_nchain.assign(size_t(d.n_nodes), -1);
+    for (int32_t n = 0; n < d.n_nodes; n = d.node_subtree_end[n]) c.emit(n, {});
+    for (int32_t n = 0; n < d.n_nodes; ++n) {
+        int32_t k = d.node_kind[n];
+        if (k <= RT_SMOOTH_TRIANGLE) {
+            out.node_nchain[size_t(n)] = c.nchain_offset(n);
+            if (k == RT_SMOOTH_TRIANGLE) out.has_smooth = true;
+            if (!d.node_casts_shadow[n]) out.all_cast_shadow = false;
+        }
+    }
+    if (out.bvh_max_depth + 2 > BVH_STACK) {
+        err = "BVH deeper than the device traversal stack";
+        return RT_ERR_UNSUPPORTED;
+    }
+    return RT_OK;
+}
+
+}  // namespace rt

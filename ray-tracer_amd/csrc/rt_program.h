@@ -1,0 +1,75 @@
+// rt_program.h — what rt_scene_create compiles the flattened scene (rt_abi.h) into before upload:
+// a linear traversal program over the reference's scene graph plus a conservative BVH per triangle mesh.
+//
+// Nothing here changes results.  The reference's own Group box gate (src/group.rs:52-53, src/bound.rs:85-116) is
+// semantic and is replayed literally as ITEM_GATE; the BVH is an acceleration over real triangle bounds that the
+// reference does not have (its triangle groups have infinite boxes: src/triangle.rs:93-95 + src/bound.rs:35-47)
+// and is built so that it never culls an intersection the reference arithmetic would report.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+
+namespace rt {
+
+enum ItemType : int32_t {
+    ITEM_LEAF = 0,       // one primitive: node = leaf node index
+    ITEM_GATE = 1,       // reference Group gate: node = group node, a = group box index, skip = item after the subtree
+    ITEM_MESH = 2,       // BVH over the triangle children of one group: a = BVH root node index
+    ITEM_CSG_BEGIN = 3,  // open a CSG scratch segment: node = csg node
+    ITEM_CSG_END = 4     // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op
+};
+
+struct Item {
+    int32_t type;
+    int32_t node;
+    int32_t chain;  // offset into chain_pool: [len, xform...] non-identity inverses to apply to the WORLD ray, outermost first
+    int32_t skip;
+    int32_t a;
+    int32_t b;
+    int32_t op;
+    int32_t _pad;
+};
+
+// BVH2, children's boxes stored in the parent (one 128-byte fetch decides both children).
+struct BvhNode {
+    double lo0[3], hi0[3];
+    double lo1[3], hi1[3];
+    int32_t c0, c1;  // >= 0: inner node index;  < 0: leaf, ~c = (first_tri << 4) | (count - 1);  INT32_MIN: empty
+    int32_t _pad[6];
+};
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
+
+// Triangle copy in BVH leaf order (what the traversal kernel streams).
+struct MeshTri {
+    double p1[3], e1[3], e2[3];  // src/triangle.rs:17-21
+    int32_t node;                // leaf node index (emission order + shading look-ups)
+    int32_t smooth;              // 1 = SmoothTriangle (keeps u,v)
+};
+static_assert(sizeof(MeshTri) == 80, "MeshTri must be 80 bytes");
+
+struct Program {
+    std::vector<Item> items;
+    std::vector<int32_t> chain_pool;
+    std::vector<int32_t> node_nchain;  // per leaf node: offset into chain_pool of [len, x_leaf, x_parent, ..., x_root]
+                                       // (registry chain of src/shape.rs:394-420, identities kept)
+    std::vector<BvhNode> bvh;
+    std::vector<MeshTri> mesh_tris;
+    bool has_csg = false;
+    bool has_smooth = false;
+    bool all_cast_shadow = true;
+    int32_t max_chain = 0;
+    int32_t bvh_max_depth = 0;
+};
+
+// Validates the descriptor (pointers, index ranges, affine inverses, CSG operand ids) and compiles it.
+// Returns RT_OK or an RT_ERR_* code with `err` set.
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err);
+
+constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
+constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_STACK = 32;          // device traversal stack entries per ray
+
+}  // namespace rt

@@ -1,0 +1,216 @@
+"""Scene builders for the configurations of BASELINE.json / SURVEY.md section 8(d), written against the
+reference-shaped API of rt_amd.  All deterministic (no RNG).  Mesh assets live in tests/golden/ (they are data
+files the reference ships: teapot.obj, teapot-low.obj, test.obj, triangles.obj)."""
+import math
+import os
+
+import numpy as np
+
+import rt_amd as rt
+from rt_amd import (Axis, Camera, Light, Material, Pattern, Shape, World, rotate, scale, translate, view_transform)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PI = math.pi
+
+
+def read_asset(name):
+    with open(os.path.join(GOLDEN, name), "r") as f:
+        return f.read()
+
+
+def book_world(hsize=320, vsize=160):
+    """C1: the Ray Tracer Challenge sphere-and-plane world — three spheres of src/main.rs:220-236 on a checkered
+    plane, patterns on every sphere, one light, camera of src/main.rs:248-249 at pi/3."""
+    w = World()
+    w.lights.append(Light.point_light((-10., 10., -10.), rt.WHITE))
+    floor = Shape.plane().set_material(Material(specular=0.).with_pattern(Pattern.checkered(rt.WHITE, rt.BLACK)))
+    middle = Shape.sphere().set_transform(translate(-0.5, 1., 0.5))
+    middle.set_material(Material(color=(0.1, 1., 0.5), diffuse=0.7, specular=0.3).with_pattern(
+        Pattern.striped((0.1, 1., 0.5), (0.9, 0.2, 0.3)).set_transform(scale(0.25, 0.25, 0.25))))
+    right = Shape.sphere().set_transform(translate(1.5, 0.5, -0.5) * scale(0.5, 0.5, 0.5))
+    right.set_material(Material(color=(0.5, 1., 0.1), diffuse=0.7, specular=0.3).with_pattern(
+        Pattern.gradient((0.5, 1., 0.1), (0.1, 0.2, 1.))))
+    left = Shape.sphere().set_transform(translate(-1.5, 0.33, -0.75) * scale(0.33, 0.33, 0.33))
+    left.set_material(Material(color=(1., 0.8, 0.1), diffuse=0.7, specular=0.3, reflective=0.3).with_pattern(
+        Pattern.ring((1., 0.8, 0.1), (0.2, 0.2, 0.2)).set_transform(scale(0.2, 0.2, 0.2))))
+    w.objects += [floor, middle, right, left]
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0., 1.5, -5.), (0., 1., 0.), (0., 1., 0.))
+    return w, cam
+
+
+def teapot_low(hsize=1920, vsize=1080):
+    """C2: teapot-low.obj through the unchanged parser (16 + 112 x 135 = 15,136 flat triangles, F3) in its Group
+    (infinite box, F4), Z-up mesh rotated upright and scaled to 0.1 (det >= 1e-5, F11), one light."""
+    w = World()
+    w.lights.append(Light.point_light((-5., 10., -10.), rt.WHITE))
+    teapot, counts = rt.obj_to_group(read_asset("teapot-low.obj"))
+    teapot.set_transform(rotate(-PI / 2., Axis.X) * scale(0.1, 0.1, 0.1))
+    teapot.set_material(Material(color=(0.8, 0.3, 0.2), diffuse=0.7, specular=0.4, shininess=50.))
+    w.objects.append(teapot)
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0., 2.5, -5.), (0., 0.6, 0.), (0., 1., 0.))
+    return w, cam
+
+
+def glass_material():
+    # blue glass sphere of src/main.rs:511-516
+    return Material(color=(0., 0., 0.2), ambient=0., diffuse=0.4, specular=0.9, shininess=300., reflective=0.9,
+                    transparency=0.9, refractive_index=1.5)
+
+
+def mirror_material():
+    # mirror of src/main.rs:658-659
+    return Material(color=rt.BLACK, diffuse=0., ambient=0., specular=1., shininess=300., reflective=1.)
+
+
+def teapot_scene(hsize=1920, vsize=1080, obj_text=None):
+    """C3 (the headline workload): teapot.obj (6320 flat triangles as the reference parser yields them, F2) with a
+    glass sphere, a mirror sphere, a checkered floor and one light."""
+    w = World()
+    w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+    floor = Shape.plane().set_material(
+        Material(specular=0., reflective=0.1).with_pattern(Pattern.checkered((0.85, 0.85, 0.85), (0.25, 0.25, 0.25))))
+    teapot, counts = rt.obj_to_group(obj_text if obj_text is not None else read_asset("teapot.obj"))
+    teapot.set_transform(rotate(PI / 7., Axis.Y))
+    teapot.set_material(Material(color=(0.9, 0.55, 0.2), diffuse=0.7, specular=0.5, shininess=80.))
+    glass = Shape.sphere().set_transform(translate(-3.6, 1.2, -2.6) * scale(1.2, 1.2, 1.2)).set_material(glass_material())
+    mirror = Shape.sphere().set_transform(translate(4.2, 1.5, 0.8) * scale(1.5, 1.5, 1.5)).set_material(mirror_material())
+    w.objects += [floor, teapot, glass, mirror]
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0.5, 4.2, -10.5), (0.2, 1.2, 0.), (0., 1., 0.))
+    return w, cam
+
+
+def smooth_teapot_obj():
+    """teapot.obj with generated area-weighted vertex normals and `a//a b//b c//c` faces (F2: no bundled OBJ
+    yields SmoothTriangles, so the smooth kernel gets a generated asset).  Pure text transformation of data."""
+    verts, faces = [], []
+    for line in read_asset("teapot.obj").splitlines():
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            verts.append([float(x) for x in p[1:4]])
+        elif p[0] == "f":
+            faces.append([int(x) for x in p[1:4]])
+    v = np.array(verts)
+    n = np.zeros_like(v)
+    for a, b, c in faces:
+        fn = np.cross(v[b - 1] - v[a - 1], v[c - 1] - v[a - 1])
+        for i in (a, b, c):
+            n[i - 1] += fn
+    ln = np.linalg.norm(n, axis=1)
+    n[ln > 0] /= ln[ln > 0][:, None]
+    n[ln == 0] = (0., 1., 0.)
+    out = [f"v {x:.6f} {y:.6f} {z:.6f}" for x, y, z in v]
+    out += [f"vn {x:.6f} {y:.6f} {z:.6f}" for x, y, z in n]
+    out += [f"f {a}//{a} {b}//{b} {c}//{c}" for a, b, c in faces]
+    return "\n".join(out) + "\n"
+
+
+def smooth_teapot_alone(hsize=240, vsize=135):
+    """Smooth teapot with nothing else in the world: xs[0] is always a smooth-triangle hit, so the reference does
+    not panic (F5b) and its `u,v of xs[0]` rule (F5a) is exercised on every multi-hit ray."""
+    w = World()
+    w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+    teapot, _ = rt.obj_to_group(smooth_teapot_obj())
+    teapot.set_material(Material(color=(0.9, 0.55, 0.2), diffuse=0.7, specular=0.5, shininess=80., reflective=0.2))
+    w.objects.append(teapot)
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0.5, 4.2, -9.5), (0.2, 1.4, 0.), (0., 1., 0.))
+    return w, cam
+
+
+def mixed_scene(hsize=2560, vsize=1440):
+    """C4: cube, closed cylinder (0..1), closed cone (-1..0), CSG difference(cube, sphere), a glass sphere holding
+    an air bubble (src/main.rs:411-421) inside a larger glass cube (3-deep n1/n2), hexagon group with finite
+    gate boxes (src/lib.rs:91-126), two lights."""
+    w = World()
+    w.lights.append(Light.point_light((-8., 9., -9.), (0.8, 0.8, 0.8)))
+    w.lights.append(Light.point_light((9., 7., -6.), (0.4, 0.4, 0.45)))
+    floor = Shape.plane().set_material(
+        Material(specular=0.1, reflective=0.15).with_pattern(
+            Pattern.checkered((0.8, 0.8, 0.8), (0.3, 0.3, 0.35)).set_transform(rotate(0.3, Axis.Y))))
+    cube = Shape.cube().set_transform(translate(-4., 1., 2.) * rotate(0.5, Axis.Y)).set_material(
+        Material(color=(0.8, 0.2, 0.2), reflective=0.2).with_pattern(
+            Pattern.gradient((0.8, 0.2, 0.2), (0.2, 0.2, 0.8)).set_transform(scale(2., 2., 2.) * translate(0.5, 0., 0.))))
+    cyl = Shape.cylinder().set_minimum(0.).set_maximum(1.).set_closed(True)
+    cyl.set_transform(translate(3.5, 0., 2.5) * scale(1., 2.5, 1.)).set_material(
+        Material(color=(0.2, 0.7, 0.3), specular=0.6).with_pattern(
+            Pattern.ring_gradient((0.2, 0.7, 0.3), (0.9, 0.9, 0.2)).set_transform(scale(0.4, 0.4, 0.4))))
+    cone = Shape.cone().set_minimum(-1.).set_maximum(0.).set_closed(True)
+    cone.set_transform(translate(0.5, 2., 4.5) * scale(1.2, 2., 1.2)).set_material(Material(color=(0.9, 0.6, 0.1), shininess=30.))
+    c_left = Shape.cube().set_material(Material(color=(0.9, 0.8, 0.2)))
+    c_right = Shape.sphere().set_transform(scale(1.3, 1.3, 1.3)).set_material(Material(color=(0.9, 0.1, 0.1)))
+    csg = Shape.csg("difference", c_left, c_right)
+    csg.set_transform(translate(-1.2, 1., -1.5) * rotate(0.6, Axis.Y) * rotate(0.3, Axis.X))
+    csg.set_material(Material(color=(0.9, 0.75, 0.2), diffuse=0.8, specular=0.4, reflective=0.1))
+    glass = Material(diffuse=0.1, shininess=300., reflective=1., refractive_index=1.52, transparency=1.)
+    air = Material(diffuse=0.1, shininess=300., reflective=1., refractive_index=1., transparency=1.)
+    glass_cube = Shape.cube().set_transform(translate(2.2, 1.3, -2.2) * rotate(0.4, Axis.Y) * scale(1.3, 1.3, 1.3))
+    glass_cube.set_material(Material(color=(0.9, 1., 0.9), ambient=0., diffuse=0.2, specular=0.9, shininess=300.,
+                                     reflective=0.6, transparency=0.8, refractive_index=1.3))
+    glass_cube.set_casts_shadow(False)
+    ball = Shape.glass_sphere().set_transform(translate(2.2, 1.3, -2.2)).set_material(glass)
+    bubble = Shape.sphere().set_transform(translate(2.2, 1.3, -2.2) * scale(0.5, 0.5, 0.5)).set_material(air)
+    hexa = Shape.hexagon().set_transform(translate(-2.5, 0.6, -4.) * rotate(-PI / 6., Axis.X) * scale(1.4, 1.4, 1.4))
+    hexa.set_material(Material(color=(0.2, 0.4, 0.9), specular=0.7))
+    w.objects += [floor, cube, cyl, cone, csg, glass_cube, ball, bubble, hexa]
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0.5, 5., -11.), (0., 1., 0.), (0., 1., 0.))
+    return w, cam
+
+
+def instanced_grid(hsize=7680, vsize=4320, grid=4):
+    """C5: grid x grid separately parsed teapot.obj + triangles.obj groups, each with its own translate*scale
+    (scale >= 0.03, F11), mirror floor.  Depth 8 is chosen by the caller (render(..., depth=8))."""
+    w = World()
+    w.lights.append(Light.point_light((-10., 20., -15.), rt.WHITE))
+    floor = Shape.plane().set_material(Material(color=(0.3, 0.3, 0.35), specular=0.2, reflective=0.6))
+    w.objects.append(floor)
+    tea, tri = read_asset("teapot.obj"), read_asset("triangles.obj")
+    span = 8.0
+    for gz in range(grid):
+        for gx in range(grid):
+            x = (gx - (grid - 1) / 2.) * span
+            z = gz * span
+            t, _ = rt.obj_to_group(tea)
+            t.set_transform(translate(x, 0., z) * rotate(0.4 * (gx + 2 * gz), Axis.Y) * scale(0.9, 0.9, 0.9))
+            t.set_material(Material(color=(0.3 + 0.6 * gx / max(grid - 1, 1), 0.5, 0.9 - 0.6 * gz / max(grid - 1, 1)),
+                                    diffuse=0.7, specular=0.5, shininess=60., reflective=0.15))
+            w.objects.append(t)
+            g, _ = rt.obj_to_group(tri)
+            g.set_transform(translate(x, 3.4, z) * scale(1.5, 1.5, 1.5))
+            g.set_material(Material(color=(0.9, 0.9, 0.3), reflective=0.3))
+            w.objects.append(g)
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0., 9., -16.), (0., 1.5, span * (grid - 1) / 2.), (0., 1., 0.))
+    return w, cam
+
+
+def cover_like_scene(hsize=200, vsize=200):
+    """A many-cube/sphere scene in the spirit of render_cover_image (src/main.rs:876): exercises cubes with
+    reflective and transparent materials plus a non-shadow-casting plane backdrop."""
+    w = World()
+    w.lights.append(Light.point_light((50., 100., -50.), rt.WHITE))
+    w.lights.append(Light.point_light((-400., 50., -10.), (0.2, 0.2, 0.2)))
+    white = Material(color=rt.WHITE, diffuse=0.7, ambient=0.1, specular=0., reflective=0.1)
+    blue = Material(color=(0.537, 0.831, 0.914), diffuse=0.7, ambient=0.1, specular=0., reflective=0.1)
+    red = Material(color=(0.941, 0.322, 0.388), diffuse=0.7, ambient=0.1, specular=0., reflective=0.1)
+    backdrop = Shape.plane().set_material(Material(color=rt.WHITE, ambient=1., diffuse=0., specular=0.))
+    backdrop.set_transform(translate(0., 0., 500.) * rotate(PI / 2., Axis.X))
+    ball = Shape.sphere().set_material(Material(color=(0.373, 0.404, 0.550), diffuse=0.2, ambient=0., specular=1.,
+                                                shininess=200., reflective=0.7, transparency=0.7, refractive_index=1.5))
+    ball.set_transform(translate(1., -1., 1.) * scale(0.5, 0.5, 0.5) * scale(3.5, 3.5, 3.5))
+    w.objects += [backdrop, ball]
+    spots = [(4., 0., 0., 3., white), (8.5, 1.5, -0.5, 3.5, blue), (0., 0., 4., 3.5, red), (4., 0., 4., 2., white),
+             (7.5, 0.5, 4., 3., red), (-0.25, 0.25, 8., 3.5, white), (4., 1., 7.5, 3.5, blue), (10., 2., 7.5, 3., red),
+             (8., 2., 12., 2., white), (20., 1., 9., 2., white), (-0.5, -5., 0.25, 3.5, blue), (4., -4., 0., 3.5, red)]
+    for x, y, z, s, m in spots:
+        c = Shape.cube().set_material(m)
+        c.set_transform(translate(x, y, z) * translate(1., -1., 1.) * scale(0.5, 0.5, 0.5) * scale(s, s, s))
+        w.objects.append(c)
+    cam = Camera(hsize, vsize, 0.785)
+    cam.transform = view_transform((-6., 6., -10.), (6., 0., 6.), (-0.45, 1., 0.))
+    return w, cam
