@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native render path.
+
+Workload (BASELINE.json metric: "Mrays/sec + ms/frame, teapot.obj 1920x1080 depth-5"): configs[2] — teapot.obj as the
+reference parser loads it (6320 flat triangles) + glass sphere + mirror sphere + checkered reflective floor, one
+light, 1920x1080, depth 5 (tests/scenes.py:teapot_scene).  One "step" = one frame = Camera::render over the whole
+(hsize-1)x(vsize-1) pixel domain.  Scene tables are resident in HBM before the timed region; each step ends with the
+frame assembled in device memory on rank 0 (N > 1: shards gathered with RCCL over xGMI, then scattered).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  value = rays traced by all ranks per frame / max-over-ranks wall time per frame.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic flops per unit of work, counted from the reference formulas as written
+# (1 per f64 add/sub/mul/div/sqrt; compares, selects, abs, negation not counted).
+F_XFORM = 64          # Ray::transform: two 4x4 * tuple products (src/ray.rs:25-30)
+F_BVH_BOX = 12        # acceleration box test: 6 sub + 6 mul (reciprocal direction), min/max not counted
+F_GATE = 18           # Bound::intersects (src/bound.rs:85-116)
+F_TRI_FULL, F_TRI_DET, F_TRI_U, F_TRI_V = 55, 16, 29, 47   # Triangle::intersect exit paths (src/triangle.rs:62-87)
+F_PRIM = (38, 2, 18, 30, 36)                                # sphere, plane, cube, cylinder wall, cone wall
+F_PREPARE = 130       # prepare_computations with one parent level (60 + 70 per level)
+F_LIGHTING = 75       # Material::lighting per light (+ one powf)
+F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
+B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
+B_RAY_STATE = 170                  # bytes of level state written + read per ray (rt_device.h: Level)
+
+FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
+                              # (mandatory for reference parity) every op is a separate mul/add => half of that
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def work_flops(w):
+    full = w[3] - w[4] - w[5] - w[6]
+    f = w[0] * F_XFORM + w[1] * F_BVH_BOX + w[2] * F_GATE
+    f += full * F_TRI_FULL + w[4] * F_TRI_DET + w[5] * F_TRI_U + w[6] * F_TRI_V
+    f += sum(w[7 + k] * F_PRIM[k] for k in range(5))
+    return f
+
+
+def work_bytes(w):
+    return w[12] * B_BVH_NODE + w[3] * B_MESH_TRI
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_low", "mixed", "book", "grid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=12)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rt_amd as rt
+    import scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
+                "book": scenes.book_world, "grid": scenes.instanced_grid}
+    w, cam = builders[args.scene](args.width, args.height)
+    scene = w.scene(local_rank)          # flatten + upload + BVH build: outside the timed region
+    cd = cam.desc()
+    n_local = int(rt.lib.rt_shard_pixel_count(C.byref(cd), rank, world))
+    counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, world)) for r in range(world)]
+    n_max = max(counts)
+    shard = torch.zeros((n_max, 3), dtype=torch.float64, device=dev)
+    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(world)] if (rank == 0 and world > 1) else None
+    packed = torch.zeros((sum(counts), 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+    opts = rt.RenderOpts(max_depth=args.depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
+
+    def step(stats=None):
+        rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shard.data_ptr(), None, None,
+                                    C.byref(stats) if stats is not None else None)
+        if rc < 0:
+            raise RuntimeError(rt.last_error())
+        if world > 1:
+            dist.gather(shard, gathered, dst=0)          # RCCL gather over xGMI: no reduction, peers -> root
+            if rank == 0:
+                off = 0
+                for r in range(world):
+                    packed[off:off + counts[r]] = gathered[r][:counts[r]]
+                    off += counts[r]
+                src = packed
+        else:
+            src = shard
+        if rank == 0:
+            torch.cuda.synchronize()
+            rc = rt.lib.rt_assemble(scene, C.byref(cd), world, src.data_ptr(), None, frame.data_ptr(), None, None)
+            if rc < 0:
+                raise RuntimeError(rt.last_error())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
+    st = rt.Stats()
+    step(st)
+    ev_trace, ev_shade, ev_total, n_ev = 0.0, 0.0, 0.0, 5
+    for _ in range(n_ev):
+        s2 = rt.Stats()
+        step(s2)
+        ev_trace += s2.ms_trace / n_ev
+        ev_shade += s2.ms_shade / n_ev
+        ev_total += s2.ms_total / n_ev
+    opts.want_counters = 1
+    sc = rt.Stats()
+    step(sc)
+    opts.want_counters = 0
+    rays_local = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes],
+                              dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays_local)
+    rays = [int(x) for x in rays_local.tolist()]
+    total_rays = sum(rays[:4])
+
+    if rank == 0:
+        wt, ws = list(sc.work_trace), list(sc.work_shade)
+        n_lights = len(w.lights)
+        fl_trace = work_flops(wt)
+        fl_shade = work_flops(ws) + st.shaded_nodes * (F_PREPARE + F_LIGHTING * n_lights) + st.rays_reflect * F_REFLECT + \
+            st.rays_refract * (F_REFRACT + F_SCHLICK)
+        by_trace = work_bytes(wt) + st.rays_primary * B_RAY_STATE
+        by_shade = work_bytes(ws) + (st.rays_reflect + st.rays_refract + st.shaded_nodes) * B_RAY_STATE
+        dom = "k_shade" if ev_shade >= ev_trace else "k_trace"
+        fl, by, ms = (fl_shade, by_shade, ev_shade) if dom == "k_shade" else (fl_trace, by_trace, ev_trace)
+        n_launch = max(st.n_trace_launches, 1)
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pmc = None
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"kernel": dom, "bound": "fp64_valu", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
+                    "launches_per_frame": n_launch, "avg_launch_ms": round(ms / n_launch, 5),
+                    "algorithmic_flops_per_launch": int(fl / n_launch), "algorithmic_bytes_per_launch": int(by / n_launch),
+                    "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
+                            "reference parity forbids FMA contraction"}
+        hbm_ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline_hbm = {"kernel": dom, "bound": "hbm", "achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_ach / HBM_PEAK_GBS, 5), "traffic": pmc}
+        kernels = {"k_trace": {"ms_per_frame": round(ev_trace, 4), "algorithmic_flops": int(fl_trace), "algorithmic_bytes": int(by_trace)},
+                   "k_shade": {"ms_per_frame": round(ev_shade, 4), "algorithmic_flops": int(fl_shade), "algorithmic_bytes": int(by_shade)},
+                   "device_ms_per_frame_rank0": round(ev_total, 4)}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_bridge as ob
+            t0 = time.perf_counter()
+            ref = ob.render(w, cam, args.depth, stride=args.cpu_stride)
+            dt = time.perf_counter() - t0
+            cpu = {"value": round(ref.stats.total_rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                   "sample": "every %dth pixel in x and y of the same frame (%d primary rays, %d rays in all, %.1f s); "
+                             "C restatement of the reference (oracle/rt_oracle.c), brute force over all 6320 triangles "
+                             "per ray like the reference, -O2 -ffp-contract=off; the Rust reference itself cannot be "
+                             "built here (no rustc/cargo)" % (args.cpu_stride, ref.stats.rays_primary,
+                                                              ref.stats.total_rays, dt)}
+        out = {"metric": "Mrays/s", "value": round(total_rays / (ms_per_step * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[2]: teapot.obj (6320 flat triangles, reference parser) + glass & mirror "
+                                      "spheres + checkered floor, 1 light, %dx%d, depth %d" % (args.width, args.height, args.depth)
+                          if args.scene == "teapot" else args.scene,
+                          "scene": args.scene, "resolution": [args.width, args.height], "depth": args.depth,
+                          "parallelism": "tile-shard x%d, RCCL gather" % world if world > 1 else "single GPU"},
+               "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
+                                  "total": total_rays, "shaded_nodes": rays[4]},
+               "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -194,6 +194,18 @@ typedef struct rt_render_opts {
     void* stream;         /* hipStream_t to enqueue on, NULL = the library's own stream                 */
 } rt_render_opts;
 
+/* rows of rt_stats.work_* */
+#define RT_WORK_XFORMS 0     /* ray transforms (2 mat-vec each, src/ray.rs:25-30)   */
+#define RT_WORK_BOX_TESTS 1  /* acceleration-BVH box tests                          */
+#define RT_WORK_GATE_TESTS 2 /* reference Group gate tests (src/bound.rs:85)        */
+#define RT_WORK_TRI_TESTS 3  /* triangle tests entered                              */
+#define RT_WORK_TRI_DET_REJ 4 /*  ... rejected at |det| < EPSILON                   */
+#define RT_WORK_TRI_U_REJ 5  /*   ... rejected at u                                 */
+#define RT_WORK_TRI_V_REJ 6  /*   ... rejected at v                                 */
+#define RT_WORK_PRIM0 7      /* +0..4: sphere, plane, cube, cylinder, cone tests    */
+#define RT_WORK_BVH_NODES 12 /* BVH nodes fetched (128 B each)                      */
+#define RT_WORK_COUNT 13
+
 typedef struct rt_stats {
     /* rays actually traced, by class (BASELINE.md ray accounting) */
     int64_t rays_primary;
@@ -214,17 +226,10 @@ typedef struct rt_stats {
     double ms_resolve; /* bottom-up colour resolve        */
     int32_t n_trace_launches;
     int32_t n_shadow_launches;
-    /* algorithmic work counted by the instrumented traversal (want_counters = 1), closest-hit
-     * and shadow launches together; SURVEY.md section 8(d) constants turn these into flops/bytes */
-    int64_t work_xforms;      /* ray transforms (2 mat-vec each)            */
-    int64_t work_box_tests;   /* acceleration-BVH box tests                 */
-    int64_t work_gate_tests;  /* reference Group gate tests (bound.rs:85)   */
-    int64_t work_tri_tests;   /* triangle tests entered                     */
-    int64_t work_tri_det_rej; /*   ... rejected at |det| < EPSILON          */
-    int64_t work_tri_u_rej;   /*   ... rejected at u                        */
-    int64_t work_tri_v_rej;   /*   ... rejected at v                        */
-    int64_t work_prim_tests[5]; /* sphere, plane, cube, cylinder, cone      */
-    int64_t work_bvh_nodes;   /* BVH nodes fetched                          */
+    /* algorithmic work counted by the instrumented kernels (want_counters = 1), per kernel class; the
+     * RT_WORK_* indices name the rows, SURVEY.md section 8(d) constants turn them into flops / bytes */
+    int64_t work_trace[RT_WORK_COUNT]; /* closest-hit launches                                          */
+    int64_t work_shade[RT_WORK_COUNT]; /* shade launches (shadow + container traversals run inside them) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device-resident tables + acceleration structure + queues */

@@ -171,6 +171,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), st));
     Timer tm{s, st, stats != nullptr};
     std::vector<long long> counts;
+    unsigned long long work_prev[RT_WORK_COUNT] = {0};
     long long n = n0;
     for (int d = 0; n > 0; ++d) {
         const int remaining = max_depth - d;
@@ -187,6 +188,14 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         if (counters) launch_trace<true>(s, st, L, n); else launch_trace<false>(s, st, L, n);
         tm.end();
         if (stats) stats->n_trace_launches++;
+        if (counters && stats) {  // instrumented run: split the work counters per kernel class
+            HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int k = 0; k < RT_WORK_COUNT; ++k) {
+                stats->work_trace[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
+                work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
+            }
+        }
         tm.begin(stats ? &stats->ms_shade : nullptr);
         if (counters) launch_shade<true>(s, st, L, N, n, remaining, next_cap);
         else launch_shade<false>(s, st, L, N, n, remaining, next_cap);
@@ -194,6 +203,11 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (counters && stats)
+            for (int k = 0; k < RT_WORK_COUNT; ++k) {
+                stats->work_shade[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
+                work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
+            }
         counts.push_back(n);
         long long next = (long long)s->h_counters[CNT_NEXT];
         if (next > next_cap) {
@@ -220,15 +234,6 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         stats->rays_shadow = (int64_t)c[CNT_SHADED] * s->n_lights;
         stats->rays_container = (int64_t)c[CNT_CONTAINER];
         stats->levels = int32_t(counts.size());
-        stats->work_xforms = (int64_t)c[CNT_W_XFORMS];
-        stats->work_box_tests = (int64_t)c[CNT_W_BOX];
-        stats->work_gate_tests = (int64_t)c[CNT_W_GATE];
-        stats->work_tri_tests = (int64_t)c[CNT_W_TRI];
-        stats->work_tri_det_rej = (int64_t)c[CNT_W_TRI_DET];
-        stats->work_tri_u_rej = (int64_t)c[CNT_W_TRI_U];
-        stats->work_tri_v_rej = (int64_t)c[CNT_W_TRI_V];
-        for (int k = 0; k < 5; ++k) stats->work_prim_tests[k] = (int64_t)c[CNT_W_PRIM0 + k];
-        stats->work_bvh_nodes = (int64_t)c[CNT_W_BVH_NODES];
     }
     return RT_OK;
 }

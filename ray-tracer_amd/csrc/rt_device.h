@@ -81,6 +81,7 @@ enum Counter : int {
     CNT_W_BVH_NODES = CNT_W_PRIM0 + 5,
     CNT_COUNT
 };
+static_assert(CNT_W_BVH_NODES - CNT_W_XFORMS + 1 == RT_WORK_COUNT, "work counter rows must match rt_abi.h");
 
 struct CameraParams {
     double inv[12];

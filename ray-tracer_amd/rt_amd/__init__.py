@@ -77,9 +77,7 @@ class Stats(C.Structure):  # rt_stats
                 ("ms_total", C.c_double), ("ms_raygen", C.c_double), ("ms_trace", C.c_double),
                 ("ms_shadow", C.c_double), ("ms_collect", C.c_double), ("ms_shade", C.c_double),
                 ("ms_resolve", C.c_double), ("n_trace_launches", C.c_int32), ("n_shadow_launches", C.c_int32),
-                ("work_xforms", C.c_int64), ("work_box_tests", C.c_int64), ("work_gate_tests", C.c_int64),
-                ("work_tri_tests", C.c_int64), ("work_tri_det_rej", C.c_int64), ("work_tri_u_rej", C.c_int64),
-                ("work_tri_v_rej", C.c_int64), ("work_prim_tests", C.c_int64 * 5), ("work_bvh_nodes", C.c_int64)]
+                ("work_trace", C.c_int64 * 13), ("work_shade", C.c_int64 * 13)]
 
     @property
     def total_rays(self):
