@@ -653,3 +653,28 @@ def check_exports():
 
 
 check_exports()
+
+
+def shard_pixels(camera_desc, rank, n_ranks):
+    """Host mirror of the device slot -> pixel map (slot_to_pixel in rt_kernels.hip.h): shard-local slot i covers
+    pixel (px[i], py[i]) when valid[i].  8x8-pixel tiles of the (hsize-1)x(vsize-1) domain dealt round-robin."""
+    w, h = camera_desc.hsize - 1, camera_desc.vsize - 1
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    n = int(lib.rt_shard_pixel_count(C.byref(camera_desc), rank, n_ranks))
+    slot = np.arange(n, dtype=np.int64)
+    tile = (slot >> 6) * n_ranks + rank
+    lane = slot & 63
+    ty, tx = tile // max(tiles_x, 1), tile % max(tiles_x, 1)
+    px, py = tx * 8 + (lane & 7), ty * 8 + (lane >> 3)
+    valid = (ty < tiles_y) & (px < w) & (py < h)
+    return px.astype(np.int64), py.astype(np.int64), valid
+
+
+def assemble_host(camera_desc, n_ranks, shards):
+    """Host mirror of rt_assemble for tests of the gather plumbing: shards[r] is rank r's [count_r, C] array."""
+    ch = shards[0].shape[1]
+    frame = np.zeros((camera_desc.vsize, camera_desc.hsize, ch), dtype=shards[0].dtype)
+    for r in range(n_ranks):
+        px, py, valid = shard_pixels(camera_desc, r, n_ranks)
+        frame[py[valid], px[valid]] = shards[r][: len(px)][valid]
+    return frame

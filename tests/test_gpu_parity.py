@@ -1,0 +1,322 @@
+"""GPU parity tests: the HIP path through the C ABI against the oracle on the same inputs, the reference's own
+known-answer vectors replayed on the device, and size-independent properties at BASELINE.json's full sizes.
+
+Bars (north_star): primary-ray hit object ids bit-exact; colours: every arithmetic step is IEEE f64 in the reference's
+operand order, the only non-reproducible function is powf in the specular term (device ocml pow vs glibc pow, <= 1 ulp
+each), so colours are held to 1e-9 absolute — far inside the 1/255 quantisation tolerance the north_star states, which
+is asserted as well (0 pixels off by more than 1/255)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_bridge as ob
+import rt_amd as rt
+import scenes
+from rt_amd import Axis, Camera, Light, Material, Pattern, Shape, World, rotate, scale, translate, view_transform
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+S2 = math.sqrt(2.)
+COLOR_TOL = 1e-9
+
+
+def near(a, b, eps=1e-5):
+    return bool(np.all(np.abs(np.asarray(a, dtype=float) - np.asarray(b, dtype=float)) < eps))
+
+
+def assert_image_parity(world, cam, depth=5):
+    g = cam.render(world, depth)
+    o = ob.render(world, cam, depth)
+    assert np.array_equal(g.hit_id, o.hit_id), f"{int((g.hit_id != o.hit_id).sum())} primary hit ids differ"
+    assert np.array_equal(g.flags, o.flags)
+    err = np.abs(g.rgb - o.rgb)
+    err[np.isnan(g.rgb) & np.isnan(o.rgb)] = 0.0
+    assert float(err.max()) < COLOR_TOL, float(err.max())
+    assert int((np.abs(g.quantised() - o.quantised()) > 1).sum()) == 0
+    # ray accounting: every class equal to the oracle's
+    assert (g.stats.rays_primary, g.stats.rays_reflect, g.stats.rays_refract, g.stats.rays_shadow, g.stats.shaded_nodes) == \
+        (o.stats.rays_primary, o.stats.rays_reflect, o.stats.rays_refract, o.stats.rays_shadow, o.stats.shaded_nodes)
+    # F1: last row / column exactly 0.0
+    assert not g.rgb[-1].any() and not g.rgb[:, -1].any() and not g.hit_id[-1].any() and not g.hit_id[:, -1].any()
+    return g, o
+
+
+# ------------------------------------------------------------------ image parity on the BASELINE configs (reduced sizes)
+def test_c1_book_world_full_size():
+    assert_image_parity(*scenes.book_world(320, 160))
+
+
+def test_c2_teapot_low():
+    assert_image_parity(*scenes.teapot_low(96, 54))
+
+
+def test_c3_teapot_glass_mirror():
+    assert_image_parity(*scenes.teapot_scene(160, 90))
+
+
+def test_c3_smooth_teapot():
+    g, _ = assert_image_parity(*scenes.smooth_teapot_alone(96, 54))
+    assert not g.flags.any()
+
+
+def test_c3_smooth_teapot_with_other_shapes_flags_reference_panics():
+    # F5b: next to a plane / spheres the reference would unwrap a None u; those pixels are flagged on both sides
+    w, cam = scenes.teapot_scene(96, 54, obj_text=scenes.smooth_teapot_obj())
+    g, o = assert_image_parity(w, cam)
+    assert (g.flags & rt.RT_FLAG_REF_PANIC_UV).any()
+
+
+def test_c4_mixed_scene():
+    assert_image_parity(*scenes.mixed_scene(256, 144))
+
+
+def test_c5_instanced_grid_depth8():
+    w, cam = scenes.instanced_grid(96, 54, grid=2)
+    assert_image_parity(w, cam, depth=8)
+
+
+def test_cover_scene_two_lights():
+    assert_image_parity(*scenes.cover_like_scene(120, 120))
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_shallow_depths(depth):
+    assert_image_parity(*scenes.mixed_scene(128, 72), depth=depth)
+
+
+# ------------------------------------------------------------------ reference KATs replayed on the device
+def test_kat_render_default_world():  # camera.rs:164-178
+    w = World.default()
+    cam = Camera(11, 11, PI / 2)
+    cam.transform = view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0))
+    assert near(cam.render(w).pixel_at(5, 5), (0.38066, 0.47583, 0.2855))
+
+
+def test_kat_ray_for_pixel():  # camera.rs:130-161
+    cam = Camera(201, 101, PI / 2)
+    o, d = cam.rays_for_pixels([100, 0], [50, 0])
+    assert near(o[0], (0, 0, 0)) and near(d[0], (0, 0, -1)) and near(d[1], (0.66519, 0.33259, -0.66851))
+    cam.transform = rotate(PI / 4, Axis.Y) * translate(0., -2., 5.)
+    o, d = cam.ray_for_pixel(100, 50)
+    assert near(o, (0, 2, -5)) and near(d, (S2 / 2, 0, -S2 / 2))
+    # bit-exact against the oracle over a whole frame
+    cam = scenes.book_world(64, 32)[1]
+    xs, ys = np.meshgrid(np.arange(63), np.arange(31))
+    go, gd = cam.rays_for_pixels(xs.ravel(), ys.ravel())
+    oo, od = ob.rays_for_pixels(cam, xs.ravel(), ys.ravel())
+    assert np.array_equal(go, oo[:, :3]) and np.array_equal(gd, od[:, :3])
+
+
+def test_kat_world():  # world.rs:186-326
+    w = World.default()
+    assert [t for t, _ in w.intersect_world(((0, 0, -5), (0, 0, 1)))] == [4., 4.5, 5.5, 6.]
+    assert near(w.color_at(((0, 0, -5), (0, 1, 0))), (0, 0, 0))
+    assert near(w.color_at(((0, 0, -5), (0, 0, 1))), (0.38066, 0.47583, 0.2855))
+    assert w.is_shadowed((0, 10, 0)) == [False] and w.is_shadowed((10, -10, 10)) == [True]
+    assert w.is_shadowed((-20, 20, -20)) == [False] and w.is_shadowed((-2, 2, -2)) == [False]
+
+
+def test_kat_non_casting_object():  # world.rs:575-588 (F8)
+    sphere = Shape.sphere().set_transform(translate(0, 3, 0)).set_casts_shadow(False)
+    w = World()
+    w.objects += [sphere, Shape.plane()]
+    w.lights.append(Light.point_light((0, 10, 0), rt.WHITE))
+    assert w.is_shadowed((0, 0, 0)) == [False]
+
+
+def test_kat_reflection_and_refraction():  # world.rs:367-384, 514-572
+    ray = ((0, 0, -3), (0, -S2 / 2, S2 / 2))
+    w = World.default()
+    w.objects.append(Shape.plane().set_material(Material(reflective=0.5)).set_transform(translate(0, -1, 0)))
+    assert near(w.color_at(ray), (0.87675, 0.92434, 0.82917))
+    for mat, expect in ((dict(transparency=0.5, refractive_index=1.5), (0.93642, 0.68642, 0.68642)),
+                        (dict(reflective=0.5, transparency=0.5, refractive_index=1.5), (0.93391, 0.69643, 0.69243))):
+        w = World.default()
+        w.objects.append(Shape.plane().set_transform(translate(0, -1, 0)).set_material(Material(**mat)))
+        w.objects.append(Shape.sphere().set_material(Material(color=(1, 0, 0), ambient=0.5)).set_transform(translate(0, -3.5, -0.5)))
+        assert near(w.color_at(ray), expect)
+
+
+def test_kat_mutually_reflective_planes_terminate():  # world.rs:387-409
+    w = World()
+    w.lights.append(Light.point_light((0, 0, 0), rt.WHITE))
+    w.objects.append(Shape.plane().set_material(Material(reflective=1.)).set_transform(translate(0, -1, 0)))
+    w.objects.append(Shape.plane().set_material(Material(reflective=1.)).set_transform(translate(0, 1, 0)))
+    assert all(math.isfinite(c) for c in w.color_at(((0, 0, 0), (0, 1, 0))))
+
+
+def test_kat_groups_and_csg_lists():  # group.rs:201-241, csg.rs:254-273
+    g = Shape.group()
+    s1 = Shape.sphere()
+    s2 = Shape.sphere().set_transform(translate(0, 0, -3))
+    s3 = Shape.sphere().set_transform(translate(5, 0, 0))
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    w = World()
+    w.objects.append(g)
+    assert [i for _, i in w.intersect_world(((0, 0, -5), (0, 0, 1)))] == [s2.get_id(), s2.get_id(), s1.get_id(), s1.get_id()]
+    s, c = Shape.sphere(), Shape.cube().set_transform(translate(0, 0, 0.5))
+    w = World()
+    w.objects.append(Shape.csg("union", s, c))
+    xs = w.intersect_world(((0, 0, -5), (0, 0, 1)))
+    assert len(xs) == 2 and xs[0] == (4., s.get_id()) and xs[1] == (6.5, c.get_id())
+
+
+# ------------------------------------------------------------------ lists, shadows and arbitrary rays against the oracle
+def _random_rays(n, seed, center=(0., 1., 0.), radius=12.):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1)[:, None] * radius * rng.uniform(0.05, 1.0, size=(n, 1)) + np.asarray(center)
+    target = rng.normal(size=(n, 3)) * 1.5 + np.asarray(center)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return o, d
+
+
+@pytest.mark.parametrize("builder", [scenes.mixed_scene, scenes.book_world, scenes.cover_like_scene])
+def test_intersection_lists_match(builder):
+    w, _ = builder(32, 32)
+    o, d = _random_rays(4000, 7)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert gc.max() >= 3
+
+
+def test_intersection_lists_match_on_the_teapot():
+    w, _ = scenes.teapot_scene(32, 32)
+    o, d = _random_rays(1500, 11, center=(0., 1.5, 0.), radius=9.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+
+
+@pytest.mark.parametrize("builder", [scenes.mixed_scene, scenes.teapot_scene])
+def test_color_at_and_shadows_for_random_rays(builder):
+    w, _ = builder(32, 32)
+    n = 3000 if builder is scenes.mixed_scene else 600
+    o, d = _random_rays(n, 3)
+    g_rgb, g_id, g_fl = w.color_at_batch(o, d, 5)
+    o_rgb, o_id, o_fl = ob.color_at_batch(w, o, d, 5)
+    assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl)
+    assert float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+    assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
+
+
+def test_unbounded_cylinder_never_equal_to_itself():  # F14 end to end
+    w = World()
+    w.lights.append(Light.point_light((-5, 5, -5), rt.WHITE))
+    w.objects.append(Shape.cylinder().set_material(Material(transparency=0.9, reflective=0.5, refractive_index=1.5)))
+    w.objects.append(Shape.plane().set_transform(translate(0, -2, 0)))
+    cam = Camera(48, 48, PI / 3)
+    cam.transform = view_transform((0, 1, -5), (0, 0, 0), (0, 1, 0))
+    g = cam.render(w)
+    o = ob.render(w, cam)
+    assert np.array_equal(g.hit_id, o.hit_id)
+    assert np.array_equal(np.isnan(g.rgb), np.isnan(o.rgb)) and np.isnan(o.rgb).any()   # n1 = n2 = 0 -> NaN, as the reference
+    ok = ~np.isnan(o.rgb)
+    assert float(np.abs(g.rgb[ok] - o.rgb[ok]).max()) < COLOR_TOL
+
+
+# ------------------------------------------------------------------ edge cases of the boundary
+def test_empty_world_and_tiny_cameras():
+    w = World()
+    cam = Camera(16, 16, 1.0)
+    img = cam.render(w)
+    assert not img.rgb.any() and not img.hit_id.any()
+    w = World.default()
+    for h, v in ((1, 1), (1, 9), (9, 1), (2, 2), (9, 17)):
+        cam = Camera(h, v, 1.0)
+        cam.transform = view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0))
+        g, o = cam.render(w), ob.render(w, cam)
+        assert np.array_equal(g.rgb, o.rgb) and np.array_equal(g.hit_id, o.hit_id)
+    assert w.color_at_batch(np.zeros((0, 3)), np.zeros((0, 3)))[0].shape == (0, 3)
+
+
+def test_non_invertible_camera_is_an_error():
+    w = World.default()
+    cam = Camera(8, 8, 1.0)
+    cam.transform = scale(0., 1., 1.)
+    with pytest.raises(rt.RtError) as e:
+        cam.render(w)
+    assert e.value.code == rt.RT_ERR_UNSUPPORTED
+
+
+def test_world_without_lights_is_black_but_traced():
+    w = World.default()
+    w.lights.clear()
+    cam = Camera(32, 32, PI / 2)
+    cam.transform = view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0))
+    g, o = cam.render(w), ob.render(w, cam)
+    assert np.array_equal(g.hit_id, o.hit_id) and g.hit_id.any() and not g.rgb.any()
+
+
+# ------------------------------------------------------------------ full-size properties (the oracle is too slow here)
+def test_full_size_properties_c3():
+    w, cam = scenes.teapot_scene(1920, 1080)
+    a = cam.render(w)
+    b = cam.render(w)
+    assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.hit_id, b.hit_id)     # deterministic
+    assert not a.rgb[-1].any() and not a.rgb[:, -1].any()                            # F1
+    assert a.stats.rays_primary == 1919 * 1079
+    assert a.stats.rays_shadow == a.stats.shaded_nodes * len(w.lights)
+    assert np.isfinite(a.rgb).all() and not a.flags.any()
+    # the frame is the same however it is tile-sharded (pixel values must not depend on the partition)
+    acc = np.zeros_like(a.rgb)
+    ids = np.zeros_like(a.hit_id)
+    total = 0
+    for r in range(3):
+        s = cam.render(w, rank=r, n_ranks=3)
+        assert not (acc.any(axis=2) & s.rgb.any(axis=2)).any()
+        acc += s.rgb
+        ids += s.hit_id
+        total += s.stats.total_rays
+    assert np.array_equal(acc, a.rgb) and np.array_equal(ids, a.hit_id) and total == a.stats.total_rays
+    # oracle on a sparse pixel sample of the SAME full-size frame
+    o = ob.render(w, cam, stride=97)
+    ys, xs = np.mgrid[0:1079:97, 0:1919:97]
+    assert np.array_equal(a.hit_id[ys, xs], o.hit_id[ys, xs])
+    assert float(np.abs(a.rgb[ys, xs] - o.rgb[ys, xs]).max()) < COLOR_TOL
+
+
+def test_device_shard_path_matches_host_path():
+    import torch
+    w, cam = scenes.mixed_scene(200, 120)
+    full = cam.render(w)
+    cd = cam.desc()
+    dev = torch.device("cuda", 0)
+    n_ranks = 2
+    shards, counts = [], []
+    for r in range(n_ranks):
+        n = int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, n_ranks))
+        buf = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        ids = torch.zeros((n,), dtype=torch.int32, device=dev)
+        opts = rt.RenderOpts(max_depth=5, rank=r, n_ranks=n_ranks, want_counters=0, stream=None)
+        assert rt.lib.rt_render_shard(w.scene(), C.byref(cd), C.byref(opts), buf.data_ptr(), ids.data_ptr(), None, None) == 0
+        shards.append((buf, ids))
+        counts.append(n)
+    rgb = torch.cat([s[0] for s in shards])
+    ids = torch.cat([s[1] for s in shards])
+    frame = torch.full((120, 200, 3), -1.0, dtype=torch.float64, device=dev)
+    fid = torch.full((120, 200), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    assert rt.lib.rt_assemble(w.scene(), C.byref(cd), n_ranks, rgb.data_ptr(), ids.data_ptr(), frame.data_ptr(), fid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full.rgb) and np.array_equal(fid.cpu().numpy(), full.hit_id)
+    # and the host mirror of the scatter agrees with the device scatter
+    host = rt.assemble_host(cd, n_ranks, [s[0].cpu().numpy() for s in shards])
+    assert np.array_equal(host, full.rgb)
+
+
+def test_instrumented_counters_do_not_change_the_image():
+    w, cam = scenes.teapot_scene(160, 90)
+    a = cam.render(w)
+    b = cam.render(w, want_counters=True)
+    assert np.array_equal(a.rgb, b.rgb)
+    wt, ws = list(b.stats.work_trace), list(b.stats.work_shade)
+    assert wt[3] > 0 and wt[12] > 0 and ws[3] > 0          # triangle tests and BVH nodes were counted
+    assert wt[3] >= wt[4] + wt[5] + wt[6]
+    traced = a.stats.rays_primary + a.stats.rays_reflect + a.stats.rays_refract
+    assert wt[8] == traced and wt[7] == 2 * traced       # one plane and two spheres tested once per traced ray
