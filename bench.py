@@ -34,7 +34,8 @@ F_PREPARE = 130       # prepare_computations with one parent level (60 + 70 per 
 F_LIGHTING = 75       # Material::lighting per light (+ one powf)
 F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
 B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
-B_RAY_STATE = 170                  # bytes of level state written + read per ray (rt_device.h: Level)
+# bytes of level state read + written per ray by each stage (rt_device.h: Level columns touched)
+B_RAY_IO = {"k_trace": 48 + 29, "k_shadow": 4 + 48 + 1, "k_container": 4 + 64 + 16, "k_prepare+k_finish": 2 * 150}
 
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
@@ -145,13 +146,13 @@ def main():
     # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
     st = rt.Stats()
     step(st)
-    ev_trace, ev_shade, ev_total, n_ev = 0.0, 0.0, 0.0, 5
+    n_ev = 5
+    ev = {"ms_trace": 0.0, "ms_shadow": 0.0, "ms_collect": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
     for _ in range(n_ev):
         s2 = rt.Stats()
         step(s2)
-        ev_trace += s2.ms_trace / n_ev
-        ev_shade += s2.ms_shade / n_ev
-        ev_total += s2.ms_total / n_ev
+        for k in ev:
+            ev[k] += getattr(s2, k) / n_ev
     opts.want_counters = 1
     sc = rt.Stats()
     step(sc)
@@ -164,36 +165,42 @@ def main():
     total_rays = sum(rays[:4])
 
     if rank == 0:
-        wt, ws = list(sc.work_trace), list(sc.work_shade)
         n_lights = len(w.lights)
-        fl_trace = work_flops(wt)
-        fl_shade = work_flops(ws) + st.shaded_nodes * (F_PREPARE + F_LIGHTING * n_lights) + st.rays_reflect * F_REFLECT + \
+        works = {"k_trace": list(sc.work_trace), "k_shadow": list(sc.work_shadow), "k_container": list(sc.work_container)}
+        ms = {"k_trace": ev["ms_trace"], "k_shadow": ev["ms_shadow"], "k_container": ev["ms_collect"], "k_prepare+k_finish": ev["ms_shade"]}
+        launches = {"k_trace": st.n_trace_launches, "k_shadow": st.n_shadow_launches, "k_container": st.n_trace_launches,
+                    "k_prepare+k_finish": 2 * st.n_trace_launches}
+        rays_in = {"k_trace": st.rays_primary + st.rays_reflect + st.rays_refract, "k_shadow": st.rays_shadow,
+                   "k_container": st.rays_container}
+        flops = {k: work_flops(v) for k, v in works.items()}
+        flops["k_prepare+k_finish"] = st.shaded_nodes * (F_PREPARE + F_LIGHTING * n_lights) + st.rays_reflect * F_REFLECT + \
             st.rays_refract * (F_REFRACT + F_SCHLICK)
-        by_trace = work_bytes(wt) + st.rays_primary * B_RAY_STATE
-        by_shade = work_bytes(ws) + (st.rays_reflect + st.rays_refract + st.shaded_nodes) * B_RAY_STATE
-        dom = "k_shade" if ev_shade >= ev_trace else "k_trace"
-        fl, by, ms = (fl_shade, by_shade, ev_shade) if dom == "k_shade" else (fl_trace, by_trace, ev_trace)
-        n_launch = max(st.n_trace_launches, 1)
+        nbytes = {k: work_bytes(v) + rays_in[k] * B_RAY_IO[k] for k, v in works.items()}
+        nbytes["k_prepare+k_finish"] = (st.rays_primary + st.rays_reflect + st.rays_refract) * B_RAY_IO["k_prepare+k_finish"]
+        dom = max(("k_trace", "k_shadow", "k_container"), key=lambda k: ms[k])
+        n_launch = max(launches[dom], 1)
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pmc = None
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         roofline = {"kernel": dom, "bound": "fp64_valu", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
-                    "launches_per_frame": n_launch, "avg_launch_ms": round(ms / n_launch, 5),
-                    "algorithmic_flops_per_launch": int(fl / n_launch), "algorithmic_bytes_per_launch": int(by / n_launch),
+                    "launches_per_frame": n_launch, "avg_launch_ms": round(ms[dom] / n_launch, 5),
+                    "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
+                    "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
                             "reference parity forbids FMA contraction"}
-        hbm_ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        hbm_ach = nbytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
         roofline_hbm = {"kernel": dom, "bound": "hbm", "achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_ach / HBM_PEAK_GBS, 5), "traffic": pmc}
-        kernels = {"k_trace": {"ms_per_frame": round(ev_trace, 4), "algorithmic_flops": int(fl_trace), "algorithmic_bytes": int(by_trace)},
-                   "k_shade": {"ms_per_frame": round(ev_shade, 4), "algorithmic_flops": int(fl_shade), "algorithmic_bytes": int(by_shade)},
-                   "device_ms_per_frame_rank0": round(ev_total, 4)}
+        kernels = {k: {"ms_per_frame": round(ms[k], 4), "launches_per_frame": launches[k], "algorithmic_flops": int(flops[k]),
+                       "algorithmic_bytes": int(nbytes[k]),
+                       "tflops": round(flops[k] / (ms[k] * 1e-3) / 1e12, 4) if ms[k] > 0 else None} for k in ms}
+        kernels["device_ms_per_frame_rank0"] = round(ev["ms_total"], 4)
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -222,14 +222,15 @@ typedef struct rt_stats {
     double ms_trace;   /* closest-hit traversal launches  */
     double ms_shadow;  /* shadow traversal launches       */
     double ms_collect; /* container-list launches         */
-    double ms_shade;   /* prepare + lighting + spawn      */
+    double ms_shade;   /* k_prepare + k_finish            */
     double ms_resolve; /* bottom-up colour resolve        */
     int32_t n_trace_launches;
     int32_t n_shadow_launches;
     /* algorithmic work counted by the instrumented kernels (want_counters = 1), per kernel class; the
      * RT_WORK_* indices name the rows, SURVEY.md section 8(d) constants turn them into flops / bytes */
-    int64_t work_trace[RT_WORK_COUNT]; /* closest-hit launches                                          */
-    int64_t work_shade[RT_WORK_COUNT]; /* shade launches (shadow + container traversals run inside them) */
+    int64_t work_trace[RT_WORK_COUNT];     /* closest-hit launches (k_trace)      */
+    int64_t work_shadow[RT_WORK_COUNT];    /* shadow launches (k_shadow)          */
+    int64_t work_container[RT_WORK_COUNT]; /* container-list launches (k_container) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device-resident tables + acceleration structure + queues */

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -52,7 +53,7 @@ struct rt_scene {
     hipStream_t stream = nullptr;
     DScene ds{};
     std::vector<void*> allocs;
-    bool has_csg = false, has_smooth = false;
+    bool has_csg = false, has_smooth = false, any_transparent = false;
     int n_lights = 0;
     std::vector<LevelStore> levels;
     unsigned long long* d_counters = nullptr;
@@ -108,8 +109,9 @@ int ensure_level(rt_scene* s, size_t idx, long long cap) {
     ls.cap = 0;
     long long c = cap + cap / 8 + 1024;
     c = (c + 63) & ~63ll;
-    const size_t nd = 18, ni = 4;
-    size_t bytes = size_t(c) * (nd * sizeof(double) + ni * sizeof(int32_t) + 1);
+    const size_t nd = 18, ni = 6;
+    const size_t nl = size_t(s->n_lights > 0 ? s->n_lights : 1);
+    size_t bytes = size_t(c) * (nd * sizeof(double) + ni * sizeof(int32_t) + 1 + nl);
     HIP_TRY(hipMalloc(&ls.block, bytes));
     double* dp = static_cast<double*>(ls.block);
     double** dfields[nd] = {&ls.L.ox, &ls.L.oy, &ls.L.oz, &ls.L.dx, &ls.L.dy, &ls.L.dz, &ls.L.ht, &ls.L.hu, &ls.L.hv,
@@ -121,7 +123,13 @@ int ensure_level(rt_scene* s, size_t idx, long long cap) {
     ls.L.mode = ip + size_t(c);
     ls.L.child_refl = ip + size_t(c) * 2;
     ls.L.child_refr = ip + size_t(c) * 3;
+    ls.L.shadow_q = ip + size_t(c) * 4;
+    ls.L.cont_q = ip + size_t(c) * 5;
     ls.L.flags = reinterpret_cast<uint8_t*>(ip + size_t(c) * ni);
+    ls.L.flags32 = reinterpret_cast<uint32_t*>(ls.L.flags);
+    ls.L.shadowed = ls.L.flags + size_t(c);
+    ls.L.px = ls.L.sr; ls.L.py = ls.L.sg; ls.L.pz = ls.L.sb;
+    ls.L.nx = ls.L.k_refl; ls.L.ny = ls.L.k_transp; ls.L.nz = ls.L.k_schlick;
     ls.cap = c;
     return RT_OK;
 }
@@ -160,10 +168,16 @@ void launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
     }
 }
 template <bool COUNT>
-void launch_shade(rt_scene* s, hipStream_t st, const Level& L, const Level& N, long long n, int remaining, long long cap) {
+void launch_shadow(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+    dim3 g(blocks_for(n * (s->n_lights > 0 ? s->n_lights : 1))), b(BLOCK);  // upper bound; idle workgroups exit at once
+    if (s->has_csg) hipLaunchKernelGGL((k_shadow<true, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
+    else hipLaunchKernelGGL((k_shadow<false, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
+}
+template <bool COUNT>
+void launch_container(rt_scene* s, hipStream_t st, const Level& L, long long n) {
     dim3 g(blocks_for(n)), b(BLOCK);
-    if (s->has_csg) hipLaunchKernelGGL((k_shade<true, COUNT>), g, b, 0, st, s->ds, L, N, n, remaining, cap, s->d_counters);
-    else hipLaunchKernelGGL((k_shade<false, COUNT>), g, b, 0, st, s->ds, L, N, n, remaining, cap, s->d_counters);
+    if (s->has_csg) hipLaunchKernelGGL((k_container<true, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
+    else hipLaunchKernelGGL((k_container<false, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
 }
 
 // color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
@@ -172,6 +186,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
     Timer tm{s, st, stats != nullptr};
     std::vector<long long> counts;
     unsigned long long work_prev[RT_WORK_COUNT] = {0};
+    long long total_shaded = 0, total_walks = 0;
     long long n = n0;
     for (int d = 0; n > 0; ++d) {
         const int remaining = max_depth - d;
@@ -184,6 +199,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         const Level& L = s->levels[size_t(d)].L;
         const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
         HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_SHADOW_Q, 0, 2 * sizeof(unsigned long long), st));
         tm.begin(stats ? &stats->ms_trace : nullptr);
         if (counters) launch_trace<true>(s, st, L, n); else launch_trace<false>(s, st, L, n);
         tm.end();
@@ -196,19 +212,43 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
                 work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
             }
         }
+        dim3 g(unsigned((n + TILE - 1) / TILE)), b(BLOCK);
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        if (counters) launch_shade<true>(s, st, L, N, n, remaining, next_cap);
-        else launch_shade<false>(s, st, L, N, n, remaining, next_cap);
+        hipLaunchKernelGGL(k_prepare, g, b, 0, st, s->ds, L, n, s->d_counters);
+        tm.end();
+        if (s->n_lights > 0) {
+            tm.begin(stats ? &stats->ms_shadow : nullptr);
+            if (counters) launch_shadow<true>(s, st, L, n); else launch_shadow<false>(s, st, L, n);
+            tm.end();
+            if (stats) stats->n_shadow_launches++;
+            if (counters && stats) {
+                HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                for (int k = 0; k < RT_WORK_COUNT; ++k) {
+                    stats->work_shadow[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
+                    work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
+                }
+            }
+        }
+        if (s->any_transparent) {
+            tm.begin(stats ? &stats->ms_collect : nullptr);
+            if (counters) launch_container<true>(s, st, L, n); else launch_container<false>(s, st, L, n);
+            tm.end();
+        }
+        tm.begin(stats ? &stats->ms_shade : nullptr);
+        hipLaunchKernelGGL(k_finish, g, b, 0, st, s->ds, L, N, n, remaining, next_cap, s->d_counters);
         tm.end();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (counters && stats)
             for (int k = 0; k < RT_WORK_COUNT; ++k) {
-                stats->work_shade[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
+                stats->work_container[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
                 work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
             }
         counts.push_back(n);
+        total_shaded += (long long)s->h_counters[CNT_SHADOW_Q];
+        total_walks += (long long)s->h_counters[CNT_CONTAINER_Q];
         long long next = (long long)s->h_counters[CNT_NEXT];
         if (next > next_cap) {
             rt_set_error("internal: level %d spawned %lld rays into a queue of %lld", d, next, next_cap);
@@ -230,9 +270,9 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         const unsigned long long* c = s->h_counters;
         stats->rays_reflect = (int64_t)c[CNT_REFLECT];
         stats->rays_refract = (int64_t)c[CNT_REFRACT];
-        stats->shaded_nodes = (int64_t)c[CNT_SHADED];
-        stats->rays_shadow = (int64_t)c[CNT_SHADED] * s->n_lights;
-        stats->rays_container = (int64_t)c[CNT_CONTAINER];
+        stats->shaded_nodes = total_shaded;
+        stats->rays_shadow = total_shaded * s->n_lights;
+        stats->rays_container = total_walks;
         stats->levels = int32_t(counts.size());
     }
     return RT_OK;
@@ -411,6 +451,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->has_csg = prog.has_csg;
     s->has_smooth = prog.has_smooth;
     s->n_lights = d.n_lights;
+    for (int m = 0; m < d.n_materials; ++m) {  // does any material ever need the n1/n2 walk?
+        const double* mp = d.material_params + size_t(m) * RT_MAT_STRIDE;
+        double tr = mp[RT_MAT_TRANSPARENCY], rf = mp[RT_MAT_REFLECTIVE];
+        if (!(std::fabs(tr - 0.) < EPS) || (rf > 0. && tr > 0.)) s->any_transparent = true;
+    }
     if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&s->ev[0]) != hipSuccess || hipEventCreate(&s->ev[1]) != hipSuccess) {

@@ -60,7 +60,13 @@ struct Level {
     int32_t* mode;                        // 1 = Schlick blend (reflective > 0 && transparency > 0)
     int32_t *child_refl, *child_refr;     // index in the next level or -1 (=> BLACK)
     double *cr, *cg, *cb;                 // resolved colour of this node
-    uint8_t* flags;
+    uint8_t* flags;                       // RT_FLAG_* per ray
+    uint32_t* flags32;                    // the same bytes, for atomicOr from the queue stages
+    // between k_prepare and k_finish: world-space point / normal of the hit (aliases of sr..k_schlick)
+    double *px, *py, *pz, *nx, *ny, *nz;
+    int32_t* shadow_q;                    // ray indices queued for k_shadow
+    int32_t* cont_q;                      // ray indices queued for k_container
+    uint8_t* shadowed;                    // [ray][light]
 };
 
 // Device counters (one int64 each).
@@ -70,6 +76,8 @@ enum Counter : int {
     CNT_REFRACT,       // refraction rays spawned
     CNT_SHADED,        // nodes that hit something
     CNT_CONTAINER,     // container-walk list passes
+    CNT_SHADOW_Q,      // entries of the level's shadow queue
+    CNT_CONTAINER_Q,   // entries of the level's container queue
     CNT_W_XFORMS,
     CNT_W_BOX,
     CNT_W_GATE,

@@ -770,114 +770,246 @@ __device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, doubl
     return r0 + (1. - r0) * (x * ((x * x) * (x * x)));
 }
 
-// Kernel: shade one level.  `remaining` is the value color_at was called with at this level.
+// ---------------------------------------------------------------------------------------------------------
+// Shading of one level as four wavefront stages (each launch is dense: no lane idles through someone else's
+// traversal):
+//   k_prepare   prepare_computations for every hit; queues the hit for the shadow stage and, when its material
+//               is transparent, for the container stage (ballot-compacted queues, one atomic per wavefront)
+//   k_shadow    World::is_shadowed for every queued (hit, light)
+//   k_container the n1/n2 walk for every queued transparent hit
+//   k_finish    Material::lighting over the lights, reflected_color / refracted_color ray spawn, node record
+// Between k_prepare and k_finish the world-space point and normal live in the (not yet written) surface /
+// coefficient columns of the level, and n1/n2 in the hit-u/v columns prepare has finished reading.
+
+__device__ __forceinline__ unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// Queue appends without an atomic per wavefront (one returning atomic on one word saturates near 90 per
+// microsecond chip-wide, which at 100k wavefronts per frame costs more than the shading itself): a workgroup owns
+// a TILE of TILE_ITERS x BLOCK consecutive rays, counts its appends in a cheap first pass, reserves its slots with
+// ONE atomic per queue, then does the work in a second pass with slots known.
+constexpr int TILE_ITERS = 8;
+constexpr int TILE = TILE_ITERS * BLOCK;
+struct TileSlots {
+    int off[2][TILE_ITERS][BLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
+    long long base[2];
+};
+
+__device__ __forceinline__ bool needs_walk(const double* __restrict__ m) {
+    // n1/n2 are read only by refracted_color and schlick, both behind a transparency test
+    return !near_eq(m[RT_MAT_TRANSPARENCY], 0.) || (m[RT_MAT_REFLECTIVE] > 0. && m[RT_MAT_TRANSPARENCY] > 0.);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long n, unsigned long long* counters) {
+    __shared__ TileSlots ts;
+    const long long tile0 = (long long)blockIdx.x * TILE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- pass 1: who goes to the shadow queue (every hit) and to the container queue (transparent hits)
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        bool shaded = false, walk = false;
+        if (i < n) {
+            int key = L.hkey[i];
+            if (key >= 0) {
+                shaded = true;
+                walk = needs_walk(S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE);
+            }
+        }
+        unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
+        if (lane == 0) { ts.off[0][it][wave] = __popcll(bs); ts.off[1][it][wave] = __popcll(bw); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int q = threadIdx.x;
+        int run = 0;
+        for (int it = 0; it < TILE_ITERS; ++it)
+            for (int w = 0; w < BLOCK / 64; ++w) { int c = ts.off[q][it][w]; ts.off[q][it][w] = run; run += c; }
+        ts.base[q] = run ? (long long)atomicAdd(counters + (q == 0 ? CNT_SHADOW_Q : CNT_CONTAINER_Q), (unsigned long long)run) : 0;
+    }
+    __syncthreads();
+    // ---- pass 2: prepare_computations
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        bool shaded = false, walk = false;
+        if (i < n) {
+            int key = L.hkey[i];
+            L.child_refl[i] = -1;
+            L.child_refr[i] = -1;
+            L.mode[i] = 0;
+            if (key >= 0) {
+                shaded = true;
+                const int node = key >> 2;
+                const int kind = S.node_kind[node];
+                V3 o = mk(L.ox[i], L.oy[i], L.oz[i]), d = mk(L.dx[i], L.dy[i], L.dz[i]);
+                // src/intersection.rs:38-48
+                V3 point = vadd(o, vmul(d, L.ht[i]));  // Ray::position
+                V3 local_point = world_to_object(S, node, point);
+                V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, L.hu[i], L.hv[i]));
+                V3 eye_vector = vneg(d);
+                if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
+                L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
+                L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
+                walk = needs_walk(S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE);
+            }
+        }
+        unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
+        if (shaded) L.shadow_q[ts.base[0] + ts.off[0][it][wave] + __popcll(bs & lanes_below())] = (int32_t)i;
+        if (walk) L.cont_q[ts.base[1] + ts.off[1][it][wave] + __popcll(bw & lanes_below())] = (int32_t)i;
+    }
+}
+
+// over_point / under_point exactly as prepare_computations forms them (src/intersection.rs:50-51)
+__device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(point, vmul(normal, EPS)); }
+__device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
+
 template <bool HAS_CSG, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n, int remaining, long long next_cap,
-                                                  unsigned long long* counters) {
+__global__ __launch_bounds__(BLOCK) void k_shadow(DScene S, Level L, unsigned long long* counters) {
     __shared__ int stack[BVH_STACK * BLOCK];
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long total = (long long)counters[CNT_SHADOW_Q] * S.n_lights;
+    long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if ((long long)blockIdx.x * BLOCK >= total) return;  // whole workgroup beyond the queue
     Work w = {};
-    bool want_refl = false, want_refr = false;
-    V3 refl_o = mk(0, 0, 0), refl_d = mk(0, 0, 0), refr_o = mk(0, 0, 0), refr_d = mk(0, 0, 0);
-    bool shaded = false, walked = false;
-    if (i < n) {
-        int key = L.hkey[i];
-        L.child_refl[i] = -1;
-        L.child_refr[i] = -1;
-        if (key >= 0) {
-            shaded = true;
-            unsigned flags = L.flags[i];
-            const int node = key >> 2;
-            const int kind = S.node_kind[node];
-            V3 o = mk(L.ox[i], L.oy[i], L.oz[i]), d = mk(L.dx[i], L.dy[i], L.dz[i]);
-            const double t = L.ht[i];
-            // ---- prepare_computations, src/intersection.rs:38-53
-            V3 point = vadd(o, vmul(d, t));  // Ray::position
-            V3 local_point = world_to_object(S, node, point);
-            V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, L.hu[i], L.hv[i]));
-            V3 eye_vector = vneg(d);
-            if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
-            V3 over_point = vadd(point, vmul(normal_vector, EPS));
-            V3 under_point = vsub(point, vmul(normal_vector, EPS));
-            V3 reflect_vector = reflect(d, normal_vector);
-
-            const int mi = S.node_material[node];
-            const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
-            const int pat = S.mat_pattern[mi];
-            const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
-
-            // n1/n2 are read only by refracted_color and schlick, both behind a transparency test
-            double n1 = 0., n2 = 0.;
-            if (!near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.)) {
-                walked = true;
-                container_walk<HAS_CSG, COUNT>(S, o, d, t, node, stack, w, n1, n2, flags);
-            }
-
-            // ---- shade_hit, src/world.rs:57-66
-            V3 surface = mk(0., 0., 0.);
-            for (int l = 0; l < S.n_lights; ++l) {
-                bool shadow = is_shadowed<HAS_CSG, COUNT>(S, over_point, l, stack, w, flags);
-                surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector, shadow));
-            }
-            // ---- reflected_color, src/world.rs:109-118
-            if (!(near_eq(reflective, 0.) || remaining <= 0)) {
-                want_refl = true;
-                refl_o = over_point;
-                refl_d = reflect_vector;
-            }
-            // ---- refracted_color, src/world.rs:120-137
-            if (!(near_eq(transparency, 0.) || remaining <= 0)) {
-                double n_ratio = n1 / n2;
-                double cos_i = dot(eye_vector, normal_vector);
-                double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                if (!(sin2_t > 1.)) {
-                    double cos_t = sqrt(1. - sin2_t);
-                    refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
-                    refr_o = under_point;
-                    want_refr = true;
-                }
-            }
-            int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
-            L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
-            L.k_refl[i] = reflective;
-            L.k_transp[i] = transparency;
-            L.k_schlick[i] = mode ? schlick(eye_vector, normal_vector, n1, n2) : 0.;
-            L.mode[i] = mode;
-            L.flags[i] = (uint8_t)flags;
-        }
-    }
-    // ---- spawn: one atomic per wavefront, slots handed out by ballot + mbcnt prefix
-    unsigned long long b_refl = __ballot(want_refl), b_refr = __ballot(want_refr);
-    unsigned long long b_shaded = __ballot(shaded), b_walk = __ballot(walked);
-    int c_refl = __popcll(b_refl), c_refr = __popcll(b_refr);
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0) {
-        if (c_refl + c_refr) base = atomicAdd(counters + CNT_NEXT, (unsigned long long)(c_refl + c_refr));
-        if (c_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)c_refl);
-        if (c_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)c_refr);
-        if (b_shaded) atomicAdd(counters + CNT_SHADED, (unsigned long long)__popcll(b_shaded));
-        if (b_walk) atomicAdd(counters + CNT_CONTAINER, (unsigned long long)__popcll(b_walk));
-    }
-    base = __shfl(base, 0, 64);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (want_refl) {
-        long long s = (long long)base + __popcll(b_refl & below);
-        if (s < next_cap) {
-            N.ox[s] = refl_o.x; N.oy[s] = refl_o.y; N.oz[s] = refl_o.z;
-            N.dx[s] = refl_d.x; N.dy[s] = refl_d.y; N.dz[s] = refl_d.z;
-            L.child_refl[i] = (int)s;
-        }
-    }
-    if (want_refr) {
-        long long s = (long long)base + c_refl + __popcll(b_refr & below);
-        if (s < next_cap) {
-            N.ox[s] = refr_o.x; N.oy[s] = refr_o.y; N.oz[s] = refr_o.z;
-            N.dx[s] = refr_d.x; N.dy[s] = refr_d.y; N.dz[s] = refr_d.z;
-            L.child_refr[i] = (int)s;
-        }
+    if (j < total) {
+        const int light = (int)(j % S.n_lights);
+        const long long i = L.shadow_q[j / S.n_lights];
+        unsigned flags = 0;
+        V3 over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
+        bool sh = is_shadowed<HAS_CSG, COUNT>(S, over_point, light, stack, w, flags);
+        L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
+        if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
     }
     if (COUNT) flush_work(w, counters);
+}
+
+template <bool HAS_CSG, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_container(DScene S, Level L, unsigned long long* counters) {
+    __shared__ int stack[BVH_STACK * BLOCK];
+    const long long total = (long long)counters[CNT_CONTAINER_Q];
+    long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if ((long long)blockIdx.x * BLOCK >= total) return;
+    Work w = {};
+    if (j < total) {
+        const long long i = L.cont_q[j];
+        unsigned flags = 0;
+        double n1, n2;
+        container_walk<HAS_CSG, COUNT>(S, mk(L.ox[i], L.oy[i], L.oz[i]), mk(L.dx[i], L.dy[i], L.dz[i]), L.ht[i], L.hkey[i] >> 2,
+                                       stack, w, n1, n2, flags);
+        L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
+        L.hv[i] = n2;
+        {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish can count
+            // its spawns before it does its work
+            V3 eye_vector = vneg(mk(L.dx[i], L.dy[i], L.dz[i])), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+            double n_ratio = n1 / n2;
+            double cos_i = dot(eye_vector, normal_vector);
+            double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+            if (sin2_t > 1.) L.mode[i] = 2;
+        }
+        if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+    }
+    if (COUNT) flush_work(w, counters);
+}
+
+// `remaining` is the value color_at was called with at this level.
+__device__ __forceinline__ void spawn_wishes(const double* __restrict__ m, int mode_bits, int remaining, bool& refl, bool& refr) {
+    refl = !(near_eq(m[RT_MAT_REFLECTIVE], 0.) || remaining <= 0);                            // src/world.rs:110
+    refr = !(near_eq(m[RT_MAT_TRANSPARENCY], 0.) || remaining <= 0) && !(mode_bits & 2);      // src/world.rs:121,128
+}
+
+__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n, int remaining, long long next_cap,
+                                                   unsigned long long* counters) {
+    __shared__ TileSlots ts;
+    const long long tile0 = (long long)blockIdx.x * TILE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- pass 1: count the reflection and refraction rays this tile will spawn
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        bool want_refl = false, want_refr = false;
+        if (i < n) {
+            int key = L.hkey[i];
+            if (key >= 0) spawn_wishes(S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE, L.mode[i], remaining, want_refl, want_refr);
+        }
+        unsigned long long b0 = __ballot(want_refl), b1 = __ballot(want_refr);
+        if (lane == 0) { ts.off[0][it][wave] = __popcll(b0); ts.off[1][it][wave] = __popcll(b1); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // both kinds share the next level's queue: reflection rays of a wavefront first
+        int run = 0, n_refl = 0, n_refr = 0;
+        for (int it = 0; it < TILE_ITERS; ++it)
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                int c0 = ts.off[0][it][w], c1 = ts.off[1][it][w];
+                ts.off[0][it][w] = run; run += c0;
+                ts.off[1][it][w] = run; run += c1;
+                n_refl += c0; n_refr += c1;
+            }
+        ts.base[0] = run ? (long long)atomicAdd(counters + CNT_NEXT, (unsigned long long)run) : 0;
+        if (n_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)n_refl);
+        if (n_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)n_refr);
+    }
+    __syncthreads();
+    // ---- pass 2: shade_hit
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        bool want_refl = false, want_refr = false;
+        V3 refl_o = mk(0, 0, 0), refl_d = mk(0, 0, 0), refr_o = mk(0, 0, 0), refr_d = mk(0, 0, 0);
+        if (i < n) {
+            int key = L.hkey[i];
+            if (key >= 0) {
+                const int node = key >> 2;
+                V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
+                V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+                V3 eye_vector = vneg(d);
+                V3 over_point = over_point_of(point, normal_vector);
+                const int mi = S.node_material[node];
+                const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
+                const int pat = S.mat_pattern[mi];
+                const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
+                const bool walked = needs_walk(m);
+                const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
+                spawn_wishes(m, L.mode[i], remaining, want_refl, want_refr);
+                // src/world.rs:57-66
+                V3 surface = mk(0., 0., 0.);
+                for (int l = 0; l < S.n_lights; ++l)
+                    surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector,
+                                                     L.shadowed[i * S.n_lights + l] != 0));
+                if (want_refl) {  // reflected_color, src/world.rs:109-118
+                    refl_o = over_point;
+                    refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
+                }
+                if (want_refr) {  // refracted_color, src/world.rs:120-137 (sin2_t <= 1 established by k_container)
+                    double n_ratio = n1 / n2;
+                    double cos_i = dot(eye_vector, normal_vector);
+                    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                    double cos_t = sqrt(1. - sin2_t);
+                    refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
+                    refr_o = under_point_of(point, normal_vector);
+                }
+                int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
+                double reflectance = mode ? schlick(eye_vector, normal_vector, n1, n2) : 0.;
+                // the point / normal columns are dead from here on: they become the node record
+                L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
+                L.k_refl[i] = reflective;
+                L.k_transp[i] = transparency;
+                L.k_schlick[i] = reflectance;
+                L.mode[i] = mode;
+            }
+        }
+        unsigned long long b0 = __ballot(want_refl), b1 = __ballot(want_refr);
+        if (want_refl) {
+            long long s = ts.base[0] + ts.off[0][it][wave] + __popcll(b0 & lanes_below());
+            if (s < next_cap) {
+                N.ox[s] = refl_o.x; N.oy[s] = refl_o.y; N.oz[s] = refl_o.z;
+                N.dx[s] = refl_d.x; N.dy[s] = refl_d.y; N.dz[s] = refl_d.z;
+                L.child_refl[i] = (int)s;
+            }
+        }
+        if (want_refr) {
+            long long s = ts.base[0] + ts.off[1][it][wave] + __popcll(b1 & lanes_below());
+            if (s < next_cap) {
+                N.ox[s] = refr_o.x; N.oy[s] = refr_o.y; N.oz[s] = refr_o.z;
+                N.dx[s] = refr_d.x; N.dy[s] = refr_d.y; N.dz[s] = refr_d.z;
+                L.child_refr[i] = (int)s;
+            }
+        }
+    }
 }
 
 // Kernel: bottom-up resolve of one level == the tail of shade_hit (src/world.rs:68-78) + color_at's miss case.

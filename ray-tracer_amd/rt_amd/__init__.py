@@ -77,7 +77,8 @@ class Stats(C.Structure):  # rt_stats
                 ("ms_total", C.c_double), ("ms_raygen", C.c_double), ("ms_trace", C.c_double),
                 ("ms_shadow", C.c_double), ("ms_collect", C.c_double), ("ms_shade", C.c_double),
                 ("ms_resolve", C.c_double), ("n_trace_launches", C.c_int32), ("n_shadow_launches", C.c_int32),
-                ("work_trace", C.c_int64 * 13), ("work_shade", C.c_int64 * 13)]
+                ("work_trace", C.c_int64 * 13), ("work_shadow", C.c_int64 * 13),
+                ("work_container", C.c_int64 * 13)]
 
     @property
     def total_rays(self):

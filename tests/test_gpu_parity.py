@@ -315,7 +315,7 @@ def test_instrumented_counters_do_not_change_the_image():
     a = cam.render(w)
     b = cam.render(w, want_counters=True)
     assert np.array_equal(a.rgb, b.rgb)
-    wt, ws = list(b.stats.work_trace), list(b.stats.work_shade)
+    wt, ws = list(b.stats.work_trace), list(b.stats.work_shadow)
     assert wt[3] > 0 and wt[12] > 0 and ws[3] > 0          # triangle tests and BVH nodes were counted
     assert wt[3] >= wt[4] + wt[5] + wt[6]
     traced = a.stats.rays_primary + a.stats.rays_reflect + a.stats.rays_refract

@@ -40,7 +40,7 @@ def test_struct_sizes_match_the_header():
     # rt_camera_desc: 4 int32 + 16 + 3 doubles; rt_render_opts: 4 int32 + pointer; rt_stats: see rt_abi.h
     assert C.sizeof(rt.CameraDesc) == 16 + 19 * 8
     assert C.sizeof(rt.RenderOpts) == 24
-    assert C.sizeof(rt.Stats) == 6 * 8 + 8 + 7 * 8 + 8 + 26 * 8
+    assert C.sizeof(rt.Stats) == 6 * 8 + 8 + 7 * 8 + 8 + 39 * 8
 
 
 # ------------------------------------------------------------------ matrix.rs / transformation.rs
