@@ -39,17 +39,28 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {  // src/tuple.rs:49-52
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return vsub(v, vmul(vmul(n, 2.), dot(v, n))); }  // :54-56
 __device__ __forceinline__ bool near_eq(double a, double b) { return fabs(a - b) < EPS; }          // src/lib.rs:56
 
+// Tables every lane of a wavefront reads at the SAME index (the traversal program, its transforms, group boxes)
+// are read through the constant address space: the compiler then fetches them with scalar loads into SGPRs
+// (one request per wavefront through the scalar cache, ~4x lower latency than a vector load, no VGPRs) instead of
+// 64 identical vector loads.  Read-only use of that cache; nothing is ever written through it.
+#define RT_CONSTANT __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const RT_CONSTANT T* as_constant(const T* p) { return (const RT_CONSTANT T*)p; }
+
 // Matrix * Tuple (src/matrix.rs:171-200) for an affine matrix given as rows 0..2; point: w = 1, vector: w = 0.
-__device__ __forceinline__ V3 xf_point(const double* __restrict__ m, V3 p) {
+template <class M>
+__device__ __forceinline__ V3 xf_point(M m, V3 p) {
     return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
               ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
 }
-__device__ __forceinline__ V3 xf_vector(const double* __restrict__ m, V3 v) {
+template <class M>
+__device__ __forceinline__ V3 xf_vector(M m, V3 v) {
     return mk((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
               (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
 }
 // inverse.transpose() * vector: row r of the transpose is column r of the inverse
-__device__ __forceinline__ V3 xf_normal(const double* __restrict__ m, V3 v) {
+template <class M>
+__device__ __forceinline__ V3 xf_normal(M m, V3 v) {
     return mk((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z,
               (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
 }
@@ -170,7 +181,8 @@ __device__ __forceinline__ double max3nan(double a, double b, double c) { return
 __device__ __forceinline__ double min3nan(double a, double b, double c) { return fmin(fmin(fmin(NAN, a), b), c); }
 
 // the slab test shared by Cube::intersect (src/cube.rs:45-61) and Bound::intersects (src/bound.rs:85-98)
-__device__ __forceinline__ bool slabs(V3 o, V3 d, const double* __restrict__ box, double& tmin, double& tmax) {
+template <class B>
+__device__ __forceinline__ bool slabs(V3 o, V3 d, B box, double& tmin, double& tmax) {
     double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
     check_axis(o.x, d.x, box[0], box[3], xtmin, xtmax);
     check_axis(o.y, d.y, box[1], box[4], ytmin, ytmax);
@@ -361,19 +373,20 @@ __device__ __forceinline__ bool csg_allowed(int op, bool left_hit, bool inl, boo
     }
 }
 
-__device__ __forceinline__ void apply_chain(const DScene& S, int chain, V3& o, V3& d, unsigned& xforms) {
-    const int* __restrict__ c = S.chain_pool + chain;
-    int len = c[0];
-    for (int i = 1; i <= len; ++i) {  // Ray::transform per level, outermost first (src/shape.rs:75-76, src/ray.rs:25-30)
-        const double* __restrict__ m = S.xf + (size_t)c[i] * 12;
-        o = xf_point(m, o);
-        d = xf_vector(m, d);
-        ++xforms;
-    }
+// Minimum of a per-lane int over the wavefront (every lane must be executing).
+__device__ __forceinline__ int wave_min_i32(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
+// The item index `i` is kept wavefront-uniform: a lane whose Group gate fails does not jump, it sleeps until the
+// walk reaches the item after that group (`until`).  Items, transform chains, group boxes and loose triangles are
+// therefore fetched once per wavefront with scalar loads, and the kind switch is a scalar branch.  When every lane
+// sleeps, the walk jumps to the nearest wake-up item.  `alive` = this lane has a ray at all; callers run traverse
+// with the whole wavefront executing.
 template <bool HAS_CSG, bool COUNT, class Sink>
-__device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& sink, int* __restrict__ stack, Work& w) {
+__device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& sink, int* __restrict__ stack, Work& w,
+                                         bool alive) {
     CsgScratch* cs = nullptr;
     CsgScratch cs_storage;
     if (HAS_CSG) {
@@ -395,20 +408,31 @@ __device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& si
             sink.emit(t, key, u, v, uv);
         }
     };
-    int i = 0;
+    const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
+    const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
+    const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);
     const int n_items = S.n_items;
+    int until = alive ? 0 : n_items;
+    int i = 0;
     while (i < n_items) {
-        const Item it = S.items[i];
+        Item it;  // one 64-byte scalar fetch (member-wise: aggregates do not copy across address spaces)
+        {
+            const RT_CONSTANT Item* __restrict__ q = items + i;
+            it.type = q->type; it.node = q->node; it.skip = q->skip; it.kind = q->kind;
+            it.a = q->a; it.b = q->b; it.op = q->op; it.chain_len = q->chain_len;
+            it.x0 = q->x0; it.x1 = q->x1; it.chain = q->chain; it.p0 = q->p0; it.p1 = q->p1;
+        }
+        const bool on = i >= until;
         ++i;
         if (it.type == ITEM_CSG_BEGIN) {
-            if (HAS_CSG) {
+            if (HAS_CSG && on) {
                 if (cs->depth < CSG_DEPTH) cs->seg[cs->depth] = cs->n; else cs->flags |= RT_FLAG_LIST_OVERFLOW;
                 cs->depth++;
             }
             continue;
         }
         if (it.type == ITEM_CSG_END) {
-            if (HAS_CSG) {
+            if (HAS_CSG && on) {
                 cs->depth--;
                 int s0 = cs->depth < CSG_DEPTH ? cs->seg[cs->depth] : 0;
                 // sort the operand lists together (stable by t == by (t, key)), src/csg.rs:70-71
@@ -444,14 +468,25 @@ __device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& si
             }
             continue;
         }
+        // Ray::transform per level, outermost first (src/shape.rs:75-76, src/ray.rs:25-30)
         V3 o = ro, d = rd;
-        apply_chain(S, it.chain, o, d, w.xforms);
+        for (int k = 0; k < it.chain_len; ++k) {
+            const int x = k == 0 ? it.x0 : k == 1 ? it.x1 : pool[it.chain + 1 + k];
+            const RT_CONSTANT double* __restrict__ m = xf + (size_t)x * 12;
+            o = xf_point(m, o);
+            d = xf_vector(m, d);
+        }
+        if (COUNT && on) w.xforms += it.chain_len;
         if (it.type == ITEM_GATE) {  // Group::intersect gate, src/group.rs:52-53
-            bump<COUNT>(w.gate);
             double tmin, tmax;
-            if (!slabs(o, d, S.group_box + (size_t)it.a * 6, tmin, tmax)) i = it.skip;
+            if (on) {
+                bump<COUNT>(w.gate);
+                if (!slabs(o, d, as_constant(S.group_box) + (size_t)it.a * 6, tmin, tmax)) until = it.skip;
+            }
+            if (__ballot(i >= until) == 0) i = wave_min_i32(until);  // nobody enters the group: jump, uniformly
             continue;
         }
+        if (!on) continue;
         if (it.type == ITEM_MESH) {
             bool full_line = HAS_CSG && cs->depth > 0;  // a CSG filter needs its operands' hits behind the origin too
             bvh_traverse<COUNT>(S, it.a, o, d, sink, full_line, stack, w, out);
@@ -459,25 +494,17 @@ __device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& si
         }
         // ITEM_LEAF
         const int node = it.node;
-        const int kind = S.node_kind[node];
         auto leaf_out = [&](double t, int k, double u, double v, int uv) { out(t, node * 4 + k, u, v, uv); };
-        switch (kind) {
+        switch (it.kind) {
             case RT_SPHERE: bump<COUNT>(w.prim[0]); isect_sphere(o, d, leaf_out); break;
             case RT_PLANE: bump<COUNT>(w.prim[1]); isect_plane(o, d, leaf_out); break;
             case RT_CUBE: bump<COUNT>(w.prim[2]); isect_cube(o, d, leaf_out); break;
-            case RT_CYLINDER:
-            case RT_CONE: {
-                int p = S.node_param[node];
-                double mn = S.conic[2 * p], mx = S.conic[2 * p + 1];
-                bool closed = S.conic_closed[p] != 0;
-                if (kind == RT_CYLINDER) { bump<COUNT>(w.prim[3]); isect_cylinder(o, d, mn, mx, closed, leaf_out); }
-                else { bump<COUNT>(w.prim[4]); isect_cone(o, d, mn, mx, closed, leaf_out); }
-                break;
-            }
+            case RT_CYLINDER: bump<COUNT>(w.prim[3]); isect_cylinder(o, d, it.p0, it.p1, it.op != 0, leaf_out); break;
+            case RT_CONE: bump<COUNT>(w.prim[4]); isect_cone(o, d, it.p0, it.p1, it.op != 0, leaf_out); break;
             default: {  // RT_TRIANGLE / RT_SMOOTH_TRIANGLE outside a mesh
-                const double* __restrict__ t = S.tri + (size_t)S.node_param[node] * 12;
+                const RT_CONSTANT double* __restrict__ t = as_constant(S.tri) + (size_t)it.a * 12;
                 isect_triangle<COUNT>(o, d, mk(t[0], t[1], t[2]), mk(t[3], t[4], t[5]), mk(t[6], t[7], t[8]),
-                                      kind == RT_SMOOTH_TRIANGLE, w, leaf_out);
+                                      it.kind == RT_SMOOTH_TRIANGLE, w, leaf_out);
                 break;
             }
         }
@@ -553,13 +580,18 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, Level L, long long n,
     __shared__ int stack[BVH_STACK * BLOCK];
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     Work w = {};
+    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+    bool alive = false;
     if (i < n) {
-        V3 o = mk(L.ox[i], L.oy[i], L.oz[i]);
-        if (o.x == o.x) {
-            V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
-            ClosestSink<NEED_FIRST> sink;
-            sink.init(INFINITY);
-            traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w);
+        o = mk(L.ox[i], L.oy[i], L.oz[i]);
+        d = mk(L.dx[i], L.dy[i], L.dz[i]);
+        alive = o.x == o.x;  // NaN origin = padding slot
+    }
+    ClosestSink<NEED_FIRST> sink;
+    sink.init(INFINITY);
+    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w, alive);
+    if (i < n) {
+        if (alive) {
             double u = sink.bu, v = sink.bv;
             unsigned flags = sink.flags;
             if (NEED_FIRST && sink.best_key >= 0 && S.node_kind[sink.best_key >> 2] == RT_SMOOTH_TRIANGLE) {
@@ -701,7 +733,7 @@ __device__ __forceinline__ V3 lighting(const DScene& S, const double* __restrict
 // World::is_shadowed for one light (src/world.rs:92-107): NEAREST hit only, then `t < distance && casts_shadow` (F8)
 template <bool HAS_CSG, bool COUNT>
 __device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light, int* __restrict__ stack, Work& w,
-                                            unsigned& flags) {
+                                            unsigned& flags, bool alive) {
     const double* __restrict__ l = S.light + (size_t)light * 6;
     V3 vector = vsub(mk(l[0], l[1], l[2]), point);
     double distance = magnitude(vector);
@@ -709,7 +741,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light
     ClosestSink<false> sink;
     // hits at t >= distance cannot shadow and cannot displace a nearer hit: bound the search there
     sink.init(distance);
-    traverse<HAS_CSG, COUNT>(S, point, direction, sink, stack, w);
+    traverse<HAS_CSG, COUNT>(S, point, direction, sink, stack, w, alive);
     flags |= sink.flags;
     if (sink.best_key < 0) return false;
     return sink.best_t < distance && S.node_casts_shadow[sink.best_key >> 2] != 0;
@@ -717,20 +749,20 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light
 
 // The n1/n2 walk of prepare_computations (src/intersection.rs:54-80) over the sorted list up to the hit.
 template <bool HAS_CSG, bool COUNT>
-__device__ __noinline__ void container_walk(const DScene& S, V3 o, V3 d, double hit_t, int hit_node, int* __restrict__ stack,
-                                            Work& w, double& n1_out, double& n2_out, unsigned& flags) {
+__device__ __forceinline__ void container_walk(const DScene& S, V3 o, V3 d, double hit_t, int hit_node, int* __restrict__ stack,
+                                               Work& w, double& n1_out, double& n2_out, unsigned& flags, bool alive) {
     double lt[LIST_CAP];
     int lk[LIST_CAP];
     ListSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
-    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w);
+    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w, alive);
     flags |= sink.flags;
     int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     sort_list(lt, lk, n);
     int containers[CONTAINER_CAP];
     int nc = 0;
     double n1 = 0., n2 = 0.;
-    const int hit_cls = S.node_eq_class[hit_node];
+    const int hit_cls = alive ? S.node_eq_class[hit_node] : -1;
     for (int i = 0; i < n; ++i) {
         int node = lk[i] >> 2;
         int cls = S.node_eq_class[node];
@@ -868,12 +900,18 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DScene S, Level L, unsigned lo
     long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if ((long long)blockIdx.x * BLOCK >= total) return;  // whole workgroup beyond the queue
     Work w = {};
-    if (j < total) {
-        const int light = (int)(j % S.n_lights);
-        const long long i = L.shadow_q[j / S.n_lights];
-        unsigned flags = 0;
-        V3 over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
-        bool sh = is_shadowed<HAS_CSG, COUNT>(S, over_point, light, stack, w, flags);
+    const bool alive = j < total;
+    int light = 0;
+    long long i = 0;
+    V3 over_point = mk(0., 0., 0.);
+    if (alive) {
+        light = (int)(j % S.n_lights);
+        i = L.shadow_q[j / S.n_lights];
+        over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
+    }
+    unsigned flags = 0;
+    bool sh = is_shadowed<HAS_CSG, COUNT>(S, over_point, light, stack, w, flags, alive);
+    if (alive) {
         L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
         if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
     }
@@ -887,17 +925,27 @@ __global__ __launch_bounds__(BLOCK) void k_container(DScene S, Level L, unsigned
     long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if ((long long)blockIdx.x * BLOCK >= total) return;
     Work w = {};
-    if (j < total) {
-        const long long i = L.cont_q[j];
-        unsigned flags = 0;
-        double n1, n2;
-        container_walk<HAS_CSG, COUNT>(S, mk(L.ox[i], L.oy[i], L.oz[i]), mk(L.dx[i], L.dy[i], L.dz[i]), L.ht[i], L.hkey[i] >> 2,
-                                       stack, w, n1, n2, flags);
+    const bool alive = j < total;
+    long long i = 0;
+    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+    double hit_t = 0.;
+    int hit_node = 0;
+    if (alive) {
+        i = L.cont_q[j];
+        o = mk(L.ox[i], L.oy[i], L.oz[i]);
+        d = mk(L.dx[i], L.dy[i], L.dz[i]);
+        hit_t = L.ht[i];
+        hit_node = L.hkey[i] >> 2;
+    }
+    unsigned flags = 0;
+    double n1, n2;
+    container_walk<HAS_CSG, COUNT>(S, o, d, hit_t, hit_node, stack, w, n1, n2, flags, alive);
+    if (alive) {
         L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
         L.hv[i] = n2;
         {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish can count
             // its spawns before it does its work
-            V3 eye_vector = vneg(mk(L.dx[i], L.dy[i], L.dz[i])), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+            V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
             double n_ratio = n1 / n2;
             double cos_i = dot(eye_vector, normal_vector);
             double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
@@ -1076,14 +1124,19 @@ __global__ __launch_bounds__(BLOCK) void k_list(DScene S, long long n, const dou
                                                 int32_t* id_out) {
     __shared__ int stack[BVH_STACK * BLOCK];
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const bool alive = i < n;
     double lt[LIST_CAP];
     int lk[LIST_CAP];
     ListSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = INFINITY; sink.flags = 0;
     Work w = {};
-    traverse<HAS_CSG, false>(S, mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
-                             mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), sink, stack, w);
+    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+    if (alive) {
+        o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    }
+    traverse<HAS_CSG, false>(S, o, d, sink, stack, w, alive);
+    if (!alive) return;
     int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     sort_list(lt, lk, m);
     count[i] = sink.n;
@@ -1098,11 +1151,14 @@ template <bool HAS_CSG>
 __global__ __launch_bounds__(BLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
     __shared__ int stack[BVH_STACK * BLOCK];
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const bool alive = i < n;
     Work w = {};
     unsigned flags = 0;
-    V3 p = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
-    for (int l = 0; l < S.n_lights; ++l) out[i * S.n_lights + l] = is_shadowed<HAS_CSG, false>(S, p, l, stack, w, flags) ? 1 : 0;
+    V3 p = alive ? mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]) : mk(0., 0., 0.);
+    for (int l = 0; l < S.n_lights; ++l) {
+        bool sh = is_shadowed<HAS_CSG, false>(S, p, l, stack, w, flags, alive);
+        if (alive) out[i * S.n_lights + l] = sh ? 1 : 0;
+    }
 }
 
 // Kernel: load caller rays into level 0 (rt_color_at).

@@ -218,6 +218,13 @@ struct Compiler {
     }
 
     // ---- traversal program -----------------------------------------------------------------------------
+    void set_chain(Item& it, const std::vector<int32_t>& chain) {
+        it.chain = chain_offset(chain);
+        it.chain_len = int32_t(chain.size());
+        it.x0 = chain.size() > 0 ? chain[0] : 0;
+        it.x1 = chain.size() > 1 ? chain[1] : 0;
+    }
+
     void emit(int32_t node, std::vector<int32_t> chain) {
         int32_t x = d.node_xform[node];
         if (x != 0) chain.push_back(x);
@@ -226,7 +233,16 @@ struct Compiler {
             Item it{};
             it.type = ITEM_LEAF;
             it.node = node;
-            it.chain = chain_offset(chain);
+            it.kind = kind;
+            set_chain(it, chain);
+            if (kind == RT_CYLINDER || kind == RT_CONE) {
+                int32_t q = d.node_param[node];
+                it.p0 = d.conic_minimum[q];
+                it.p1 = d.conic_maximum[q];
+                it.op = d.conic_closed[q] ? 1 : 0;
+            } else if (is_tri_kind(kind)) {
+                it.a = d.node_param[node];
+            }
             p.items.push_back(it);
             return;
         }
@@ -242,7 +258,7 @@ struct Compiler {
                 Item it{};
                 it.type = ITEM_GATE;
                 it.node = node;
-                it.chain = chain_offset(chain);
+                set_chain(it, chain);
                 it.a = d.node_param[node];
                 gate = int32_t(p.items.size());
                 p.items.push_back(it);
@@ -255,7 +271,7 @@ struct Compiler {
                 Item it{};
                 it.type = ITEM_MESH;
                 it.node = node;
-                it.chain = chain_offset(chain);
+                set_chain(it, chain);
                 it.a = build_mesh(tris);
                 p.items.push_back(it);
             }

@@ -22,16 +22,25 @@ enum ItemType : int32_t {
     ITEM_CSG_END = 4     // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op
 };
 
+// One 64-byte record per item: everything the traversal needs for the item arrives with ONE scalar load (the
+// item index is wavefront-uniform, see traverse() in rt_kernels.hip.h), and the first two transforms of the chain
+// are named inline so that the common chains need no second dependent fetch.
 struct Item {
     int32_t type;
     int32_t node;
-    int32_t chain;  // offset into chain_pool: [len, xform...] non-identity inverses to apply to the WORLD ray, outermost first
-    int32_t skip;
-    int32_t a;
-    int32_t b;
-    int32_t op;
+    int32_t skip;       // ITEM_GATE: index of the item after the group's subtree
+    int32_t kind;       // ITEM_LEAF: RT_* kind of the node
+    int32_t a;          // GATE: group box index; MESH: BVH root; CSG_END: first node of the left operand;
+                        // LEAF triangle: triangle index
+    int32_t b;          // CSG_END: end of the left operand's node range
+    int32_t op;         // CSG_END: csg op;  LEAF cylinder / cone: closed
+    int32_t chain_len;  // non-identity inverses to apply to the WORLD ray, outermost first
+    int32_t x0, x1;     // the first two of them
+    int32_t chain;      // offset into chain_pool of [len, xform...] (read only when chain_len > 2)
     int32_t _pad;
+    double p0, p1;      // LEAF cylinder / cone: minimum, maximum
 };
+static_assert(sizeof(Item) == 64, "Item must be 64 bytes");
 
 // BVH2, children's boxes stored in the parent (one 128-byte fetch decides both children).
 struct BvhNode {
