@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,10 @@ struct rt_scene {
     unsigned long long* h_counters = nullptr;  // pinned
     GrowBuf out_rgb, out_id, out_flags, frame_rgb, frame_id, frame_flags, in_a, in_b, misc_a, misc_b, misc_c;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
+    size_t trav_lds_bytes = 0;
+    int n_cus = 1;
+    std::map<const void*, int> trav_grid;  // kernel -> workgroups that are resident at once on the whole device
 };
 
 namespace {
@@ -156,28 +161,45 @@ struct Timer {  // accumulates device time of bracketed launches when enabled
     }
 };
 
-template <bool COUNT>
-void launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
-    dim3 g(blocks_for(n)), b(BLOCK);
-    if (s->has_csg) {
-        if (s->has_smooth) hipLaunchKernelGGL((k_trace<true, true, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
-        else hipLaunchKernelGGL((k_trace<true, false, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
-    } else {
-        if (s->has_smooth) hipLaunchKernelGGL((k_trace<false, true, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
-        else hipLaunchKernelGGL((k_trace<false, false, COUNT>), g, b, 0, st, s->ds, L, n, s->d_counters);
+// Launches a persistent traversal kernel over `n_chunks` chunks of TBLOCK rays (an upper bound is fine: the kernel
+// derives its own chunk count).  The grid is what the device can hold at once with this kernel's LDS footprint.
+template <class K, class... A>
+int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... args) {
+    const void* key = reinterpret_cast<const void*>(kernel);
+    auto it = s->trav_grid.find(key);
+    if (it == s->trav_grid.end()) {
+        HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, int(s->trav_lds_bytes)));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBLOCK, s->trav_lds_bytes));
+        if (per_cu < 1) { rt_set_error("traversal kernel does not fit a compute unit with %zu bytes of LDS", s->trav_lds_bytes); return RT_ERR_HIP; }
+        it = s->trav_grid.emplace(key, per_cu * s->n_cus).first;
     }
+    long long grid = std::min<long long>(n_chunks, it->second);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kernel, dim3(unsigned(grid)), dim3(TBLOCK), s->trav_lds_bytes, st, args...);
+    return RT_OK;
+}
+inline long long chunks_for(long long n) { return (n + TBLOCK - 1) / TBLOCK; }
+
+template <bool COUNT>
+int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+    if (s->has_csg) {
+        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
+        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
+    }
+    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
+    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
 }
 template <bool COUNT>
-void launch_shadow(rt_scene* s, hipStream_t st, const Level& L, long long n) {
-    dim3 g(blocks_for(n * (s->n_lights > 0 ? s->n_lights : 1))), b(BLOCK);  // upper bound; idle workgroups exit at once
-    if (s->has_csg) hipLaunchKernelGGL((k_shadow<true, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
-    else hipLaunchKernelGGL((k_shadow<false, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
+int launch_shadow(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+    const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1));  // the queue length lives on the device
+    if (s->has_csg) return launch_trav(s, st, k_shadow<true, COUNT>, upper, s->ds, L, s->d_counters);
+    return launch_trav(s, st, k_shadow<false, COUNT>, upper, s->ds, L, s->d_counters);
 }
 template <bool COUNT>
-void launch_container(rt_scene* s, hipStream_t st, const Level& L, long long n) {
-    dim3 g(blocks_for(n)), b(BLOCK);
-    if (s->has_csg) hipLaunchKernelGGL((k_container<true, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
-    else hipLaunchKernelGGL((k_container<false, COUNT>), g, b, 0, st, s->ds, L, s->d_counters);
+int launch_container(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+    if (s->has_csg) return launch_trav(s, st, k_container<true, COUNT>, chunks_for(n), s->ds, L, s->d_counters);
+    return launch_trav(s, st, k_container<false, COUNT>, chunks_for(n), s->ds, L, s->d_counters);
 }
 
 // color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
@@ -201,7 +223,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(s->d_counters + CNT_SHADOW_Q, 0, 2 * sizeof(unsigned long long), st));
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        if (counters) launch_trace<true>(s, st, L, n); else launch_trace<false>(s, st, L, n);
+        { int rc = counters ? launch_trace<true>(s, st, L, n) : launch_trace<false>(s, st, L, n); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
         if (counters && stats) {  // instrumented run: split the work counters per kernel class
@@ -214,11 +236,11 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         }
         dim3 g(unsigned((n + TILE - 1) / TILE)), b(BLOCK);
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_prepare, g, b, 0, st, s->ds, L, n, s->d_counters);
+        hipLaunchKernelGGL(k_prepare, g, b, 0, st, s->ds, L, n, remaining, s->d_counters);
         tm.end();
         if (s->n_lights > 0) {
             tm.begin(stats ? &stats->ms_shadow : nullptr);
-            if (counters) launch_shadow<true>(s, st, L, n); else launch_shadow<false>(s, st, L, n);
+            { int rc = counters ? launch_shadow<true>(s, st, L, n) : launch_shadow<false>(s, st, L, n); if (rc != RT_OK) return rc; }
             tm.end();
             if (stats) stats->n_shadow_launches++;
             if (counters && stats) {
@@ -232,7 +254,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         }
         if (s->any_transparent) {
             tm.begin(stats ? &stats->ms_collect : nullptr);
-            if (counters) launch_container<true>(s, st, L, n); else launch_container<false>(s, st, L, n);
+            { int rc = counters ? launch_container<true>(s, st, L, n) : launch_container<false>(s, st, L, n); if (rc != RT_OK) return rc; }
             tm.end();
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
@@ -448,6 +470,17 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->ds.n_nodes = d.n_nodes;
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
+    s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));
+    s->trav_lds_bytes = prog.bvh.empty() ? 0 : size_t(s->ds.n_lds) * sizeof(BvhNode) + size_t(BVH_STACK) * TBLOCK * sizeof(int);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { rt_set_error("hipGetDeviceProperties failed"); return fail(RT_ERR_HIP); }
+        s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    }
+    for (int m = 0; m < d.n_materials; ++m) {  // see needs_walk (rt_kernels.hip.h)
+        double ri = d.material_params[size_t(m) * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        if (!(std::isfinite(ri) && ri > 0.)) s->ds.walk_at_zero = 1;
+    }
     s->has_csg = prog.has_csg;
     s->has_smooth = prog.has_smooth;
     s->n_lights = d.n_lights;
@@ -611,15 +644,15 @@ int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const
     HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->misc_b.p, 0, lb * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(s->misc_c.p, 0, lb * sizeof(int32_t), st));
-    dim3 g(blocks_for(n_rays)), b(BLOCK);
     if (s->has_csg)
-        hipLaunchKernelGGL((k_list<true>), g, b, 0, st, s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
-                           static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
-                           static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+        rc = launch_trav(s, st, k_list<true>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+                         static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
+                         static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
     else
-        hipLaunchKernelGGL((k_list<false>), g, b, 0, st, s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
-                           static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
-                           static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+        rc = launch_trav(s, st, k_list<false>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+                         static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
+                         static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(count_out, s->misc_a.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(t_out, s->misc_b.p, lb * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -642,13 +675,13 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
     size_t rb = size_t(n_points) * 3 * sizeof(double), ob = size_t(n_points) * size_t(s->n_lights);
     if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->misc_a, ob)) != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
-    dim3 g(blocks_for(n_points)), b(BLOCK);
     if (s->has_csg)
-        hipLaunchKernelGGL((k_shadow_points<true>), g, b, 0, st, s->ds, (long long)n_points, static_cast<const double*>(s->in_a.p),
-                           static_cast<uint8_t*>(s->misc_a.p));
+        rc = launch_trav(s, st, k_shadow_points<true>, chunks_for(n_points), s->ds, (long long)n_points,
+                         static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
     else
-        hipLaunchKernelGGL((k_shadow_points<false>), g, b, 0, st, s->ds, (long long)n_points, static_cast<const double*>(s->in_a.p),
-                           static_cast<uint8_t*>(s->misc_a.p));
+        rc = launch_trav(s, st, k_shadow_points<false>, chunks_for(n_points), s->ds, (long long)n_points,
+                         static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, s->misc_a.p, ob, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

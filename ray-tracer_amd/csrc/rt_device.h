@@ -8,7 +8,9 @@
 namespace rt {
 
 constexpr double EPS = 0.00001;   // EPSILON, src/lib.rs:42
-constexpr int BLOCK = 256;        // 4 wavefronts
+constexpr int BLOCK = 256;        // 4 wavefronts: streaming kernels
+constexpr int TBLOCK = 512;       // 8 wavefronts: traversal kernels (they share one LDS copy of the BVH top levels)
+constexpr int LDS_NODE_CAP = 768; // BVH4 nodes staged in LDS: 96 KiB + 64 KiB of per-lane stacks = the CU's 160 KiB
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
 constexpr int LIST_CAP = 64;      // per-ray list for the n1/n2 container walk and rt_intersect_world
@@ -47,6 +49,9 @@ struct DScene {
     const BvhNode* bvh;
     const MeshTri* mesh_tris;
     int32_t all_cast_shadow;
+    int32_t n_lds;                    // BVH nodes [0, n_lds) are staged in LDS by the traversal kernels
+    int32_t walk_at_zero;             // 1: some refractive index is not finite-positive, so the n1/n2 walk cannot be
+                                      //    skipped at remaining == 0 (see needs_walk)
     int32_t _pad;
 };
 

@@ -290,14 +290,23 @@ __device__ __forceinline__ void isect_triangle(V3 o, V3 d, V3 point1, V3 edge_ve
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Acceleration BVH over one triangle mesh (non-semantic: only decides which triangles get tested).
-// Boxes are padded on the host; the slab test below is deliberately loose (NaN-ignoring min/max, relative slack).
+// Acceleration BVH4 over the triangle meshes (non-semantic: only decides which triangles get tested).
+// Boxes are padded on the host and stored as outward-rounded f32; the slab test below runs in f64 and is
+// deliberately loose (NaN-ignoring min/max, relative slack).  The first `n_lds` nodes (the top levels of every
+// mesh, rt_program.h) are read from the workgroup's LDS copy, the rest from L2/HBM.
 
-__device__ __forceinline__ bool bvh_box(const double* __restrict__ lo, const double* __restrict__ hi, V3 o, V3 inv,
+#define RT_LDS __attribute__((address_space(3)))
+struct TravMem {
+    const RT_LDS BvhNode* lds_nodes;  // workgroup copy of S.bvh[0 .. n_lds)
+    int n_lds;
+    RT_LDS int* stack;                // [BVH_STACK][TBLOCK], one column per lane
+};
+
+__device__ __forceinline__ bool bvh_box(double lox, double loy, double loz, double hix, double hiy, double hiz, V3 o, V3 inv,
                                         double tlo, double thi, double& tnear) {
-    double ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-    double ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-    double az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    double ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    double ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    double az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
     double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
     double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
     tnear = tmin;
@@ -306,49 +315,91 @@ __device__ __forceinline__ bool bvh_box(const double* __restrict__ lo, const dou
     return !(tmin > tmax + slack) && !(tmax < tlo - slack) && !(tmin > thi + slack);
 }
 
+struct TriData {
+    V3 p1, e1, e2;
+    int node, smooth;
+};
+__device__ __forceinline__ TriData load_tri(const MeshTri* __restrict__ t) {
+    TriData r;
+    r.p1 = mk(t->p1[0], t->p1[1], t->p1[2]);
+    r.e1 = mk(t->e1[0], t->e1[1], t->e1[2]);
+    r.e2 = mk(t->e2[0], t->e2[1], t->e2[2]);
+    r.node = t->node;
+    r.smooth = t->smooth;
+    return r;
+}
+
+__device__ __forceinline__ void cswap(double& ta, int& ca, double& tb, int& cb) {
+    if (tb < ta) { double t = ta; ta = tb; tb = t; int c = ca; ca = cb; cb = c; }
+}
+
 template <bool COUNT, class Sink, class E>
-__device__ __forceinline__ void bvh_traverse(const DScene& S, int root, V3 o, V3 d, const Sink& sink, bool full_line,
-                                             int* __restrict__ stack, Work& w, E&& e) {
-    V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+__device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, const Sink& sink,
+                                             bool full_line, Work& w, E&& e) {
+    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     const int tid = threadIdx.x;
     int sp = 0;
     int cur = root;
     while (true) {
-        const BvhNode* __restrict__ n = S.bvh + cur;
-        bump<COUNT>(w.bvh_nodes);
-        bump<COUNT>(w.box, 2);
-        double tlo = full_line ? -INFINITY : sink.lo();
-        double thi = sink.hi();
-        double n0, n1;
-        bool h0 = n->c0 != INT32_MIN && bvh_box(n->lo0, n->hi0, o, inv, tlo, thi, n0);
-        bool h1 = n->c1 != INT32_MIN && bvh_box(n->lo1, n->hi1, o, inv, tlo, thi, n1);
-        int c0 = n->c0, c1 = n->c1;
-        if (h0 && h1 && n1 < n0) { int t = c0; c0 = c1; c1 = t; }  // nearer child first
-        else if (!h0 && h1) { c0 = c1; h0 = true; h1 = false; }
-        int next = -1;
+        if (cur >= 0) {
+            // ---- inner node: one 128-byte record decides four children
+            float lo[3][4], hi[3][4];
+            int ch[4];
+            if (cur < M.n_lds) {
+                const RT_LDS BvhNode* __restrict__ n = M.lds_nodes + cur;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            bool hit = side == 0 ? h0 : h1;
-            int c = side == 0 ? c0 : c1;
-            if (!hit) continue;
-            if (c >= 0) {
-                if (next < 0) next = c;
-                else stack[sp++ * BLOCK + tid] = c;
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { lo[a][c] = n->lo[a][c]; hi[a][c] = n->hi[a][c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ch[c] = n->child[c];
             } else {
-                int code = ~c;
-                int first = code >> 4, count = (code & 15) + 1;
-                for (int i = 0; i < count; ++i) {
-                    const MeshTri* __restrict__ t = S.mesh_tris + first + i;
-                    int node = t->node;
-                    isect_triangle<COUNT>(o, d, mk(t->p1[0], t->p1[1], t->p1[2]), mk(t->e1[0], t->e1[1], t->e1[2]),
-                                          mk(t->e2[0], t->e2[1], t->e2[2]), t->smooth, w,
-                                          [&](double tt, int k, double u, double v, int uv) { e(tt, node * 4 + k, u, v, uv); });
-                }
+                const BvhNode* __restrict__ n = S.bvh + cur;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { lo[a][c] = n->lo[a][c]; hi[a][c] = n->hi[a][c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ch[c] = n->child[c];
             }
+            bump<COUNT>(w.bvh_nodes);
+            bump<COUNT>(w.box, 4);
+            const double tlo = full_line ? -INFINITY : sink.lo();
+            const double thi = sink.hi();
+            double tn[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double t;
+                bool hit = ch[c] != INT32_MIN &&
+                           bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
+                                   (double)hi[2][c], o, inv, tlo, thi, t);
+                tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
+                if (!hit) ch[c] = INT32_MIN;
+            }
+            // nearest first (order only matters for how soon the closest-hit bound tightens)
+            cswap(tn[0], ch[0], tn[1], ch[1]);
+            cswap(tn[2], ch[2], tn[3], ch[3]);
+            cswap(tn[0], ch[0], tn[2], ch[2]);
+            cswap(tn[1], ch[1], tn[3], ch[3]);
+            cswap(tn[1], ch[1], tn[2], ch[2]);
+            if (ch[3] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[3];
+            if (ch[2] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[2];
+            if (ch[1] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[1];
+            if (ch[0] != INT32_MIN) { cur = ch[0]; continue; }
+        } else {
+            // ---- leaf: its (at most BVH_LEAF_MAX = 2) triangles arrive as one batch of loads
+            const int code = ~cur;
+            const int first = code >> 2, count = (code & 3) + 1;
+            const TriData ta = load_tri(S.mesh_tris + first);
+            const TriData tb = load_tri(S.mesh_tris + first + (count > 1 ? 1 : 0));
+            isect_triangle<COUNT>(o, d, ta.p1, ta.e1, ta.e2, ta.smooth, w,
+                                  [&](double tt, int k, double u, double v, int uv) { e(tt, ta.node * 4 + k, u, v, uv); });
+            if (count > 1)
+                isect_triangle<COUNT>(o, d, tb.p1, tb.e1, tb.e2, tb.smooth, w,
+                                      [&](double tt, int k, double u, double v, int uv) { e(tt, tb.node * 4 + k, u, v, uv); });
         }
-        if (next >= 0) { cur = next; continue; }
         if (sp == 0) break;
-        cur = stack[--sp * BLOCK + tid];
+        cur = M.stack[--sp * TBLOCK + tid];
     }
 }
 
@@ -385,8 +436,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // sleeps, the walk jumps to the nearest wake-up item.  `alive` = this lane has a ray at all; callers run traverse
 // with the whole wavefront executing.
 template <bool HAS_CSG, bool COUNT, class Sink>
-__device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& sink, int* __restrict__ stack, Work& w,
-                                         bool alive) {
+__device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive) {
     CsgScratch* cs = nullptr;
     CsgScratch cs_storage;
     if (HAS_CSG) {
@@ -489,7 +539,7 @@ __device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& si
         if (!on) continue;
         if (it.type == ITEM_MESH) {
             bool full_line = HAS_CSG && cs->depth > 0;  // a CSG filter needs its operands' hits behind the origin too
-            bvh_traverse<COUNT>(S, it.a, o, d, sink, full_line, stack, w, out);
+            bvh_traverse<COUNT>(S, M, it.a, o, d, sink, full_line, w, out);
             continue;
         }
         // ITEM_LEAF
@@ -510,6 +560,24 @@ __device__ __forceinline__ void traverse(const DScene& S, V3 ro, V3 rd, Sink& si
         }
     }
     if (HAS_CSG) sink.flags |= cs->flags;
+}
+
+// Traversal kernels are persistent: a grid of as many 512-lane workgroups as fit the chip, each staging the BVH top
+// levels into LDS once and then walking chunks of TBLOCK rays (chunk c belongs to workgroup c % gridDim.x, so heavy
+// image regions are dealt round-robin over the CUs).  Dynamic LDS layout: [n_lds BvhNode][BVH_STACK x TBLOCK int].
+__device__ __forceinline__ TravMem trav_setup(const DScene& S) {
+    extern __shared__ __align__(16) unsigned char trav_lds[];
+    TravMem M;
+    M.n_lds = S.n_lds;
+    M.lds_nodes = (const RT_LDS BvhNode*)trav_lds;
+    M.stack = (RT_LDS int*)(trav_lds + (size_t)S.n_lds * sizeof(BvhNode));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(S.bvh);
+    RT_LDS u32x4* dst = (RT_LDS u32x4*)trav_lds;
+    const int n16 = S.n_lds * int(sizeof(BvhNode) / 16);
+    for (int k = threadIdx.x; k < n16; k += TBLOCK) dst[k] = src[k];
+    __syncthreads();
+    return M;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -576,34 +644,37 @@ __global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long 
 // Kernel: closest hit for one level == intersect_world + Intersection::hit (+ which u,v normal_at will see).
 
 template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, Level L, long long n, unsigned long long* counters) {
-    __shared__ int stack[BVH_STACK * BLOCK];
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n, unsigned long long* counters) {
+    const TravMem M = trav_setup(S);
     Work w = {};
-    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-    bool alive = false;
-    if (i < n) {
-        o = mk(L.ox[i], L.oy[i], L.oz[i]);
-        d = mk(L.dx[i], L.dy[i], L.dz[i]);
-        alive = o.x == o.x;  // NaN origin = padding slot
-    }
-    ClosestSink<NEED_FIRST> sink;
-    sink.init(INFINITY);
-    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w, alive);
-    if (i < n) {
-        if (alive) {
-            double u = sink.bu, v = sink.bv;
-            unsigned flags = sink.flags;
-            if (NEED_FIRST && sink.best_key >= 0 && S.node_kind[sink.best_key >> 2] == RT_SMOOTH_TRIANGLE) {
-                if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
-                else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
+    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const long long i = c * TBLOCK + threadIdx.x;
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        bool alive = false;
+        if (i < n) {
+            o = mk(L.ox[i], L.oy[i], L.oz[i]);
+            d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            alive = o.x == o.x;  // NaN origin = padding slot
+        }
+        ClosestSink<NEED_FIRST> sink;
+        sink.init(INFINITY);
+        traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
+        if (i < n) {
+            if (alive) {
+                double u = sink.bu, v = sink.bv;
+                unsigned flags = sink.flags;
+                if (NEED_FIRST && sink.best_key >= 0 && S.node_kind[sink.best_key >> 2] == RT_SMOOTH_TRIANGLE) {
+                    if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+                    else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+                }
+                L.ht[i] = sink.best_t; L.hu[i] = u; L.hv[i] = v;
+                L.hkey[i] = sink.best_key;
+                L.flags[i] = (uint8_t)flags;
+            } else {
+                L.hkey[i] = -1;
+                L.flags[i] = 0;
             }
-            L.ht[i] = sink.best_t; L.hu[i] = u; L.hv[i] = v;
-            L.hkey[i] = sink.best_key;
-            L.flags[i] = (uint8_t)flags;
-        } else {
-            L.hkey[i] = -1;
-            L.flags[i] = 0;
         }
     }
     if (COUNT) flush_work(w, counters);
@@ -732,8 +803,8 @@ __device__ __forceinline__ V3 lighting(const DScene& S, const double* __restrict
 
 // World::is_shadowed for one light (src/world.rs:92-107): NEAREST hit only, then `t < distance && casts_shadow` (F8)
 template <bool HAS_CSG, bool COUNT>
-__device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light, int* __restrict__ stack, Work& w,
-                                            unsigned& flags, bool alive) {
+__device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V3 point, int light, Work& w, unsigned& flags,
+                                            bool alive) {
     const double* __restrict__ l = S.light + (size_t)light * 6;
     V3 vector = vsub(mk(l[0], l[1], l[2]), point);
     double distance = magnitude(vector);
@@ -741,7 +812,7 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light
     ClosestSink<false> sink;
     // hits at t >= distance cannot shadow and cannot displace a nearer hit: bound the search there
     sink.init(distance);
-    traverse<HAS_CSG, COUNT>(S, point, direction, sink, stack, w, alive);
+    traverse<HAS_CSG, COUNT>(S, M, point, direction, sink, w, alive);
     flags |= sink.flags;
     if (sink.best_key < 0) return false;
     return sink.best_t < distance && S.node_casts_shadow[sink.best_key >> 2] != 0;
@@ -749,13 +820,13 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, V3 point, int light
 
 // The n1/n2 walk of prepare_computations (src/intersection.rs:54-80) over the sorted list up to the hit.
 template <bool HAS_CSG, bool COUNT>
-__device__ __forceinline__ void container_walk(const DScene& S, V3 o, V3 d, double hit_t, int hit_node, int* __restrict__ stack,
-                                               Work& w, double& n1_out, double& n2_out, unsigned& flags, bool alive) {
+__device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M, V3 o, V3 d, double hit_t, int hit_node, Work& w,
+                                               double& n1_out, double& n2_out, unsigned& flags, bool alive) {
     double lt[LIST_CAP];
     int lk[LIST_CAP];
     ListSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
-    traverse<HAS_CSG, COUNT>(S, o, d, sink, stack, w, alive);
+    traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
     flags |= sink.flags;
     int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     sort_list(lt, lk, n);
@@ -826,12 +897,17 @@ struct TileSlots {
     long long base[2];
 };
 
-__device__ __forceinline__ bool needs_walk(const double* __restrict__ m) {
-    // n1/n2 are read only by refracted_color and schlick, both behind a transparency test
+__device__ __forceinline__ bool needs_walk(const DScene& S, const double* __restrict__ m, int remaining) {
+    // n1/n2 are read only by refracted_color and schlick, both behind a transparency test.  At remaining <= 0
+    // refracted_color and reflected_color return BLACK before using them (src/world.rs:110,121) and schlick's result
+    // only scales those two BLACKs: any FINITE reflectance gives surface + 0 + 0.  It is finite whenever every
+    // refractive index in the scene is finite and positive (S.walk_at_zero == 0), so the walk is skipped there and
+    // k_finish records reflectance 0.
+    if (remaining <= 0 && !S.walk_at_zero) return false;
     return !near_eq(m[RT_MAT_TRANSPARENCY], 0.) || (m[RT_MAT_REFLECTIVE] > 0. && m[RT_MAT_TRANSPARENCY] > 0.);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long n, unsigned long long* counters) {
+__global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long n, int remaining, unsigned long long* counters) {
     __shared__ TileSlots ts;
     const long long tile0 = (long long)blockIdx.x * TILE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -843,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long 
             int key = L.hkey[i];
             if (key >= 0) {
                 shaded = true;
-                walk = needs_walk(S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE);
+                walk = needs_walk(S, S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE, remaining);
             }
         }
         unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
@@ -880,7 +956,7 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long 
                 if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
                 L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
                 L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
-                walk = needs_walk(S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE);
+                walk = needs_walk(S, S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE, remaining);
             }
         }
         unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
@@ -894,64 +970,68 @@ __device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(p
 __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
 
 template <bool HAS_CSG, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shadow(DScene S, Level L, unsigned long long* counters) {
-    __shared__ int stack[BVH_STACK * BLOCK];
+__global__ __launch_bounds__(TBLOCK) void k_shadow(DScene S, Level L, unsigned long long* counters) {
+    const TravMem M = trav_setup(S);
     const long long total = (long long)counters[CNT_SHADOW_Q] * S.n_lights;
-    long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if ((long long)blockIdx.x * BLOCK >= total) return;  // whole workgroup beyond the queue
+    const long long n_chunks = (total + TBLOCK - 1) / TBLOCK;
     Work w = {};
-    const bool alive = j < total;
-    int light = 0;
-    long long i = 0;
-    V3 over_point = mk(0., 0., 0.);
-    if (alive) {
-        light = (int)(j % S.n_lights);
-        i = L.shadow_q[j / S.n_lights];
-        over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
-    }
-    unsigned flags = 0;
-    bool sh = is_shadowed<HAS_CSG, COUNT>(S, over_point, light, stack, w, flags, alive);
-    if (alive) {
-        L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
-        if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const long long j = c * TBLOCK + threadIdx.x;
+        const bool alive = j < total;
+        int light = 0;
+        long long i = 0;
+        V3 over_point = mk(0., 0., 0.);
+        if (alive) {
+            light = (int)(j % S.n_lights);
+            i = L.shadow_q[j / S.n_lights];
+            over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
+        }
+        unsigned flags = 0;
+        bool sh = is_shadowed<HAS_CSG, COUNT>(S, M, over_point, light, w, flags, alive);
+        if (alive) {
+            L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
+            if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+        }
     }
     if (COUNT) flush_work(w, counters);
 }
 
 template <bool HAS_CSG, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_container(DScene S, Level L, unsigned long long* counters) {
-    __shared__ int stack[BVH_STACK * BLOCK];
+__global__ __launch_bounds__(TBLOCK) void k_container(DScene S, Level L, unsigned long long* counters) {
+    const TravMem M = trav_setup(S);
     const long long total = (long long)counters[CNT_CONTAINER_Q];
-    long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if ((long long)blockIdx.x * BLOCK >= total) return;
+    const long long n_chunks = (total + TBLOCK - 1) / TBLOCK;
     Work w = {};
-    const bool alive = j < total;
-    long long i = 0;
-    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-    double hit_t = 0.;
-    int hit_node = 0;
-    if (alive) {
-        i = L.cont_q[j];
-        o = mk(L.ox[i], L.oy[i], L.oz[i]);
-        d = mk(L.dx[i], L.dy[i], L.dz[i]);
-        hit_t = L.ht[i];
-        hit_node = L.hkey[i] >> 2;
-    }
-    unsigned flags = 0;
-    double n1, n2;
-    container_walk<HAS_CSG, COUNT>(S, o, d, hit_t, hit_node, stack, w, n1, n2, flags, alive);
-    if (alive) {
-        L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
-        L.hv[i] = n2;
-        {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish can count
-            // its spawns before it does its work
-            V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-            double n_ratio = n1 / n2;
-            double cos_i = dot(eye_vector, normal_vector);
-            double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-            if (sin2_t > 1.) L.mode[i] = 2;
+    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const long long j = c * TBLOCK + threadIdx.x;
+        const bool alive = j < total;
+        long long i = 0;
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        double hit_t = 0.;
+        int hit_node = 0;
+        if (alive) {
+            i = L.cont_q[j];
+            o = mk(L.ox[i], L.oy[i], L.oz[i]);
+            d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            hit_t = L.ht[i];
+            hit_node = L.hkey[i] >> 2;
         }
-        if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+        unsigned flags = 0;
+        double n1, n2;
+        container_walk<HAS_CSG, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
+        if (alive) {
+            L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
+            L.hv[i] = n2;
+            {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish can
+                // count its spawns before it does its work
+                V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+                double n_ratio = n1 / n2;
+                double cos_i = dot(eye_vector, normal_vector);
+                double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                if (sin2_t > 1.) L.mode[i] = 2;
+            }
+            if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+        }
     }
     if (COUNT) flush_work(w, counters);
 }
@@ -1010,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
                 const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
                 const int pat = S.mat_pattern[mi];
                 const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
-                const bool walked = needs_walk(m);
+                const bool walked = needs_walk(S, m, remaining);
                 const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
                 spawn_wishes(m, L.mode[i], remaining, want_refl, want_refr);
                 // src/world.rs:57-66
@@ -1031,7 +1111,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
                     refr_o = under_point_of(point, normal_vector);
                 }
                 int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
-                double reflectance = mode ? schlick(eye_vector, normal_vector, n1, n2) : 0.;
+                double reflectance = mode && walked ? schlick(eye_vector, normal_vector, n1, n2) : 0.;  // see needs_walk
                 // the point / normal columns are dead from here on: they become the node record
                 L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
                 L.k_refl[i] = reflective;
@@ -1119,45 +1199,51 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_
 
 // Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
 template <bool HAS_CSG>
-__global__ __launch_bounds__(BLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
-                                                const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
-                                                int32_t* id_out) {
-    __shared__ int stack[BVH_STACK * BLOCK];
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const bool alive = i < n;
-    double lt[LIST_CAP];
-    int lk[LIST_CAP];
-    ListSink sink;
-    sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = INFINITY; sink.flags = 0;
-    Work w = {};
-    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-    if (alive) {
-        o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
-        d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-    }
-    traverse<HAS_CSG, false>(S, o, d, sink, stack, w, alive);
-    if (!alive) return;
-    int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
-    sort_list(lt, lk, m);
-    count[i] = sink.n;
-    for (int k = 0; k < m && k < max_hits; ++k) {
-        t_out[i * max_hits + k] = lt[k];
-        id_out[i * max_hits + k] = S.node_object_id[lk[k] >> 2];
+__global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
+                                                 const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
+                                                 int32_t* id_out) {
+    const TravMem M = trav_setup(S);
+    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
+    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const long long i = c * TBLOCK + threadIdx.x;
+        const bool alive = i < n;
+        double lt[LIST_CAP];
+        int lk[LIST_CAP];
+        ListSink sink;
+        sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = INFINITY; sink.flags = 0;
+        Work w = {};
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        if (alive) {
+            o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+            d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+        }
+        traverse<HAS_CSG, false>(S, M, o, d, sink, w, alive);
+        if (!alive) continue;
+        int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
+        sort_list(lt, lk, m);
+        count[i] = sink.n;
+        for (int k = 0; k < m && k < max_hits; ++k) {
+            t_out[i * max_hits + k] = lt[k];
+            id_out[i * max_hits + k] = S.node_object_id[lk[k] >> 2];
+        }
     }
 }
 
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
 template <bool HAS_CSG>
-__global__ __launch_bounds__(BLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
-    __shared__ int stack[BVH_STACK * BLOCK];
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const bool alive = i < n;
-    Work w = {};
-    unsigned flags = 0;
-    V3 p = alive ? mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]) : mk(0., 0., 0.);
-    for (int l = 0; l < S.n_lights; ++l) {
-        bool sh = is_shadowed<HAS_CSG, false>(S, p, l, stack, w, flags, alive);
-        if (alive) out[i * S.n_lights + l] = sh ? 1 : 0;
+__global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
+    const TravMem M = trav_setup(S);
+    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
+    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const long long i = c * TBLOCK + threadIdx.x;
+        const bool alive = i < n;
+        Work w = {};
+        unsigned flags = 0;
+        V3 p = alive ? mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]) : mk(0., 0., 0.);
+        for (int l = 0; l < S.n_lights; ++l) {
+            bool sh = is_shadowed<HAS_CSG, false>(S, M, p, l, w, flags, alive);
+            if (alive) out[i * S.n_lights + l] = sh ? 1 : 0;
+        }
     }
 }
 

@@ -66,9 +66,18 @@ struct Compiler {
         }
     };
     double pad = 0.;
-    int depth_seen = 0;
-
     static constexpr int32_t EMPTY = std::numeric_limits<int32_t>::min();
+
+    // binary tree of one mesh, before the collapse
+    struct Node2 {
+        Box box[2];
+        int32_t child[2];  // >= 0: Node2 index; < 0: leaf reference (final encoding)
+    };
+    std::vector<Node2> n2;
+    // BVH4 nodes of all meshes in creation order, with their depth; reordered by depth at the end
+    std::vector<BvhNode> n4;
+    std::vector<int32_t> n4_depth;
+    std::vector<size_t> mesh_items;  // items whose `a` is a root index into n4
 
     int32_t emit_leaf(std::vector<TriRef>& refs, size_t lo, size_t hi) {
         int32_t first = int32_t(p.mesh_tris.size());
@@ -85,12 +94,11 @@ struct Compiler {
             mt.smooth = d.node_kind[node] == RT_SMOOTH_TRIANGLE ? 1 : 0;
             p.mesh_tris.push_back(mt);
         }
-        return ~((first << 4) | int32_t(hi - lo - 1));
+        return ~((first << 2) | int32_t(hi - lo - 1));
     }
 
-    // Builds [lo,hi) and returns the child reference plus its (padded) box.
+    // Builds [lo,hi) as a binary tree and returns the child reference plus its (padded) box.
     int32_t build(std::vector<TriRef>& refs, size_t lo, size_t hi, Box& box, int depth) {
-        depth_seen = std::max(depth_seen, depth);
         box.reset();
         Box cb;
         cb.reset();
@@ -111,8 +119,8 @@ struct Compiler {
         bool split_done = false;
         int lg = 0;
         while ((size_t(1) << lg) < n) ++lg;
-        // SAH may unbalance the tree; allow it only while a median-split subtree would still fit the device stack
-        if (ext > 0. && depth + lg + 2 < BVH_STACK) {
+        // SAH may unbalance the tree; allow it only while a median-split subtree would still fit the depth bound
+        if (ext > 0. && depth + lg + 2 < BVH2_MAX_DEPTH) {
             constexpr int NB = 16;
             Box bb[NB];
             size_t cnt[NB] = {0};
@@ -167,24 +175,73 @@ struct Compiler {
                                  [&](const TriRef& a, const TriRef& b) { return a.c[axis] < b.c[axis]; });
             // ext == 0: all centroids coincide (e.g. repeated fan triangles, F3) — halve by index
         }
-        int32_t me = int32_t(p.bvh.size());
-        p.bvh.emplace_back();
+        int32_t me = int32_t(n2.size());
+        n2.emplace_back();
         Box b0, b1;
         int32_t c0 = build(refs, lo, mid, b0, depth + 1);
         int32_t c1 = build(refs, mid, hi, b1, depth + 1);
-        BvhNode& nd = p.bvh[size_t(me)];
+        Node2& nd = n2[size_t(me)];
+        nd.box[0] = b0; nd.box[1] = b1;
+        nd.child[0] = c0; nd.child[1] = c1;
+        return me;
+    }
+
+    static float round_down(double x) {
+        float f = float(x);
+        if (double(f) > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+        return f;
+    }
+    static float round_up(double x) {
+        float f = float(x);
+        if (double(f) < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        return f;
+    }
+
+    // Collapses the binary subtree under Node2 `root2` into one BVH4 node (children expanded breadth first, so every
+    // BVH4 level consumes two binary levels wherever two exist) and recurses.  Returns the n4 index.
+    int32_t collapse(int32_t root2, int depth) {
+        struct Slot { int32_t ref; Box box; };
+        std::vector<Slot> slots;
+        const Node2 r = n2[size_t(root2)];
+        auto expand = [&](const Slot& sl) {
+            const Node2 c = n2[size_t(sl.ref)];
+            slots.push_back({c.child[0], c.box[0]});
+            slots.push_back({c.child[1], c.box[1]});
+        };
+        const Slot a{r.child[0], r.box[0]}, b{r.child[1], r.box[1]};
+        if (a.ref >= 0) expand(a); else slots.push_back(a);
+        if (b.ref >= 0) expand(b); else slots.push_back(b);
+        if (slots.size() == 3) {  // one original was a leaf: a grandchild may be opened too
+            for (size_t s = 0; s < 3; ++s)
+                if (slots[s].ref >= 0) {
+                    const Node2 c = n2[size_t(slots[s].ref)];
+                    slots[s] = {c.child[0], c.box[0]};
+                    slots.insert(slots.begin() + long(s) + 1, {c.child[1], c.box[1]});
+                    break;
+                }
+        }
+        int32_t me = int32_t(n4.size());
+        n4.emplace_back();
+        n4_depth.push_back(depth);
+        p.bvh_max_depth = std::max(p.bvh_max_depth, depth + 1);
+        BvhNode nd;
         std::memset(&nd, 0, sizeof nd);
-        for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
-        nd.c0 = c0;
-        nd.c1 = c1;
+        for (int c = 0; c < 4; ++c) {
+            if (size_t(c) < slots.size()) {
+                for (int k = 0; k < 3; ++k) { nd.lo[k][c] = round_down(slots[size_t(c)].box.lo[k]); nd.hi[k][c] = round_up(slots[size_t(c)].box.hi[k]); }
+                nd.child[c] = slots[size_t(c)].ref >= 0 ? collapse(slots[size_t(c)].ref, depth + 1) : slots[size_t(c)].ref;
+            } else {
+                for (int k = 0; k < 3; ++k) { nd.lo[k][c] = float(INF); nd.hi[k][c] = float(-INF); }
+                nd.child[c] = EMPTY;
+            }
+        }
+        n4[size_t(me)] = nd;
         return me;
     }
 
     int32_t build_mesh(const std::vector<int32_t>& tri_nodes) {
         std::vector<TriRef> refs(tri_nodes.size());
         double maxabs = 0.;
-        Box all;
-        all.reset();
         for (size_t i = 0; i < tri_nodes.size(); ++i) {
             TriRef& r = refs[i];
             r.node = tri_nodes[i];
@@ -196,25 +253,40 @@ struct Compiler {
                 r.c[k] = 0.5 * r.lo[k] + 0.5 * r.hi[k];
                 maxabs = std::max(maxabs, std::max(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
             }
-            all.add(r.lo, r.hi);
         }
         // Conservative padding: the reference accepts u,v in [0,1] as COMPUTED (relative error ~1e-16) and our
         // p2/p3 are re-derived from edges; 1e-7 of the mesh scale is nine orders of magnitude above both.
         pad = 1e-7 * maxabs + 1e-300;
+        n2.clear();
         Box rb;
         int32_t root = build(refs, 0, refs.size(), rb, 0);
         if (root < 0) {  // the whole mesh is one leaf: wrap it in a node
-            int32_t me = int32_t(p.bvh.size());
-            p.bvh.emplace_back();
-            BvhNode& nd = p.bvh[size_t(me)];
-            std::memset(&nd, 0, sizeof nd);
-            for (int k = 0; k < 3; ++k) { nd.lo0[k] = rb.lo[k]; nd.hi0[k] = rb.hi[k]; nd.lo1[k] = INF; nd.hi1[k] = -INF; }
-            nd.c0 = root;
-            nd.c1 = EMPTY;
-            root = me;
+            Node2 nd;
+            nd.box[0] = rb;
+            nd.box[1].reset();
+            nd.child[0] = root;
+            nd.child[1] = EMPTY;
+            n2.push_back(nd);
+            root = int32_t(n2.size()) - 1;
         }
-        p.bvh_max_depth = std::max(p.bvh_max_depth, depth_seen);
-        return root;
+        return collapse(root, 0);
+    }
+
+    // Orders the BVH4 nodes of all meshes by depth (stable), rewrites child links and the mesh items' roots.
+    void finish_bvh() {
+        std::vector<int32_t> order(n4.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = int32_t(i);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n4_depth[size_t(a)] < n4_depth[size_t(b)]; });
+        std::vector<int32_t> where(n4.size());
+        for (size_t i = 0; i < order.size(); ++i) where[size_t(order[i])] = int32_t(i);
+        p.bvh.resize(n4.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            BvhNode nd = n4[size_t(order[i])];
+            for (int c = 0; c < 4; ++c)
+                if (nd.child[c] >= 0) nd.child[c] = where[size_t(nd.child[c])];
+            p.bvh[i] = nd;
+        }
+        for (size_t it : mesh_items) p.items[it].a = where[size_t(p.items[it].a)];
     }
 
     // ---- traversal program -----------------------------------------------------------------------------
@@ -273,6 +345,7 @@ struct Compiler {
                 it.node = node;
                 set_chain(it, chain);
                 it.a = build_mesh(tris);
+                mesh_items.push_back(p.items.size());
                 p.items.push_back(it);
             }
             for (int32_t c = node + 1; c < d.node_subtree_end[node]; c = d.node_subtree_end[c]) {
@@ -411,7 +484,8 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err) {
             if (!d.node_casts_shadow[n]) out.all_cast_shadow = false;
         }
     }
-    if (out.bvh_max_depth + 2 > BVH_STACK) {
+    c.finish_bvh();
+    if (3 * out.bvh_max_depth + 1 > BVH_STACK) {
         err = "BVH deeper than the device traversal stack";
         return RT_ERR_UNSUPPORTED;
     }

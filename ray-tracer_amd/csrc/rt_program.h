@@ -42,12 +42,15 @@ struct Item {
 };
 static_assert(sizeof(Item) == 64, "Item must be 64 bytes");
 
-// BVH2, children's boxes stored in the parent (one 128-byte fetch decides both children).
+// BVH4: the four children's boxes are stored in the parent (one 128-byte fetch decides all four), as f32 rounded
+// OUTWARD from the padded f64 boxes — the device converts back to f64 (exact) and tests in f64, so a stored box
+// always contains the f64 box it came from.  Nodes of all meshes are ordered by depth, so that any prefix of the
+// array is "the top levels" — that prefix is what the traversal kernels stage in LDS.
 struct BvhNode {
-    double lo0[3], hi0[3];
-    double lo1[3], hi1[3];
-    int32_t c0, c1;  // >= 0: inner node index;  < 0: leaf, ~c = (first_tri << 4) | (count - 1);  INT32_MIN: empty
-    int32_t _pad[6];
+    float lo[3][4];    // [axis][child]
+    float hi[3][4];
+    int32_t child[4];  // >= 0: inner node index;  < 0: leaf, ~c = (first_tri << 2) | (count - 1);  INT32_MIN: empty
+    int32_t _pad[4];
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 
@@ -78,7 +81,8 @@ struct Program {
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err);
 
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
-constexpr int BVH_LEAF_MAX = 4;
-constexpr int BVH_STACK = 32;          // device traversal stack entries per ray
+constexpr int BVH_LEAF_MAX = 2;        // triangles per leaf (the device fetches a leaf's triangles as one batch)
+constexpr int BVH_STACK = 32;          // device traversal stack entries per ray: 3 pending siblings per BVH4 level
+constexpr int BVH2_MAX_DEPTH = 20;     // binary build depth bound; the collapse halves it: 3 * 10 <= BVH_STACK
 
 }  // namespace rt
