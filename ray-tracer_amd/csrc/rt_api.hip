@@ -204,7 +204,7 @@ int launch_container(rt_scene* s, hipStream_t st, const Level& L, long long n) {
 
 // color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
 int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool counters, rt_stats* stats) {
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_COUNT * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_TOTAL * sizeof(unsigned long long), st));
     Timer tm{s, st, stats != nullptr};
     std::vector<long long> counts;
     unsigned long long work_prev[RT_WORK_COUNT] = {0};
@@ -220,8 +220,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         }
         const Level& L = s->levels[size_t(d)].L;
         const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
-        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_SHADOW_Q, 0, 2 * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, (CNT_TOTAL - CNT_NEXT) * sizeof(unsigned long long), st));
         tm.begin(stats ? &stats->ms_trace : nullptr);
         { int rc = counters ? launch_trace<true>(s, st, L, n) : launch_trace<false>(s, st, L, n); if (rc != RT_OK) return rc; }
         tm.end();
@@ -471,11 +470,20 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
     s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));
-    s->trav_lds_bytes = prog.bvh.empty() ? 0 : size_t(s->ds.n_lds) * sizeof(BvhNode) + size_t(BVH_STACK) * TBLOCK * sizeof(int);
+    s->trav_lds_bytes = prog.bvh.empty() ? 0 : size_t(s->ds.n_lds) * sizeof(BvhNode) + size_t(LDS_STACK) * TBLOCK * sizeof(int);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { rt_set_error("hipGetDeviceProperties failed"); return fail(RT_ERR_HIP); }
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        // stack rows beyond LDS_STACK, one column per lane that can be resident (2048 lanes per CU at most)
+        s->ds.spill_lanes = (long long)s->n_cus * 2048;
+        void* sp = nullptr;
+        if (hipMalloc(&sp, size_t(BVH_STACK - LDS_STACK) * size_t(s->ds.spill_lanes) * sizeof(int32_t)) != hipSuccess) {
+            rt_set_error("could not allocate the traversal stack spill area");
+            return fail(RT_ERR_HIP);
+        }
+        s->allocs.push_back(sp);
+        s->ds.spill = static_cast<int32_t*>(sp);
     }
     for (int m = 0; m < d.n_materials; ++m) {  // see needs_walk (rt_kernels.hip.h)
         double ri = d.material_params[size_t(m) * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
@@ -489,7 +497,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         double tr = mp[RT_MAT_TRANSPARENCY], rf = mp[RT_MAT_REFLECTIVE];
         if (!(std::fabs(tr - 0.) < EPS) || (rf > 0. && tr > 0.)) s->any_transparent = true;
     }
-    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&s->ev[0]) != hipSuccess || hipEventCreate(&s->ev[1]) != hipSuccess) {
         rt_set_error("could not create stream / counters: %s", hipGetErrorString(hipGetLastError()));

@@ -9,8 +9,11 @@ namespace rt {
 
 constexpr double EPS = 0.00001;   // EPSILON, src/lib.rs:42
 constexpr int BLOCK = 256;        // 4 wavefronts: streaming kernels
-constexpr int TBLOCK = 512;       // 8 wavefronts: traversal kernels (they share one LDS copy of the BVH top levels)
-constexpr int LDS_NODE_CAP = 768; // BVH4 nodes staged in LDS: 96 KiB + 64 KiB of per-lane stacks = the CU's 160 KiB
+constexpr int TBLOCK = 1024;      // 16 wavefronts: traversal kernels (they share one LDS copy of the BVH top levels)
+constexpr int LDS_STACK = 12;     // traversal stack entries per lane kept in LDS; deeper entries spill to HBM (rare)
+constexpr int LDS_NODE_CAP = 895; // BVH4 nodes staged in LDS: ~112 KiB + 48 KiB of per-lane stacks + the feed word <= 160 KiB
+constexpr int FEED_PARTS = 8;     // chunk-feed counters per traversal kernel, one cache line each
+constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
 constexpr int LIST_CAP = 64;      // per-ray list for the n1/n2 container walk and rt_intersect_world
@@ -53,6 +56,8 @@ struct DScene {
     int32_t walk_at_zero;             // 1: some refractive index is not finite-positive, so the n1/n2 walk cannot be
                                       //    skipped at remaining == 0 (see needs_walk)
     int32_t _pad;
+    int32_t* spill;                   // [BVH_STACK - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
+    long long spill_lanes;
 };
 
 // One recursion level: the ray queue and, index for index, the nodes of the ray tree at that depth.
@@ -76,13 +81,10 @@ struct Level {
 
 // Device counters (one int64 each).
 enum Counter : int {
-    CNT_NEXT = 0,      // rays appended to the next level
-    CNT_REFLECT,       // reflection rays spawned
+    CNT_REFLECT = 0,   // reflection rays spawned
     CNT_REFRACT,       // refraction rays spawned
     CNT_SHADED,        // nodes that hit something
     CNT_CONTAINER,     // container-walk list passes
-    CNT_SHADOW_Q,      // entries of the level's shadow queue
-    CNT_CONTAINER_Q,   // entries of the level's container queue
     CNT_W_XFORMS,
     CNT_W_BOX,
     CNT_W_GATE,
@@ -92,9 +94,19 @@ enum Counter : int {
     CNT_W_TRI_V,
     CNT_W_PRIM0,       // +0..4: sphere, plane, cube, cylinder, cone
     CNT_W_BVH_NODES = CNT_W_PRIM0 + 5,
-    CNT_COUNT
+    // ---- zeroed together before every level (one memset from CNT_NEXT to CNT_TOTAL)
+    CNT_NEXT,          // rays appended to the next level
+    CNT_SHADOW_Q,      // entries of the level's shadow queue
+    CNT_CONTAINER_Q,   // entries of the level's container queue
+    CNT_COUNT,         // what the host reads back
+    // chunk feeds of the persistent traversal kernels: FEED_PARTS counters per kernel, FEED_STRIDE apart
+    CNT_FEED_TRACE = 32,
+    CNT_FEED_SHADOW = CNT_FEED_TRACE + FEED_PARTS * FEED_STRIDE,
+    CNT_FEED_CONTAINER = CNT_FEED_SHADOW + FEED_PARTS * FEED_STRIDE,
+    CNT_TOTAL = CNT_FEED_CONTAINER + FEED_PARTS * FEED_STRIDE
 };
 static_assert(CNT_W_BVH_NODES - CNT_W_XFORMS + 1 == RT_WORK_COUNT, "work counter rows must match rt_abi.h");
+static_assert(CNT_COUNT <= CNT_FEED_TRACE, "feed counters overlap the plain ones");
 
 struct CameraParams {
     double inv[12];

@@ -299,8 +299,17 @@ __device__ __forceinline__ void isect_triangle(V3 o, V3 d, V3 point1, V3 edge_ve
 struct TravMem {
     const RT_LDS BvhNode* lds_nodes;  // workgroup copy of S.bvh[0 .. n_lds)
     int n_lds;
-    RT_LDS int* stack;                // [BVH_STACK][TBLOCK], one column per lane
+    RT_LDS int* stack;                // [LDS_STACK][TBLOCK], one column per lane
+    int* spill;                       // this lane's column of the HBM spill area, rows spill_lanes apart
+    long long spill_lanes;
 };
+__device__ __forceinline__ void stack_push(const TravMem& M, int sp, int v) {
+    if (sp < LDS_STACK) M.stack[sp * TBLOCK + threadIdx.x] = v;
+    else M.spill[(long long)(sp - LDS_STACK) * M.spill_lanes] = v;
+}
+__device__ __forceinline__ int stack_pop(const TravMem& M, int sp) {
+    return sp < LDS_STACK ? M.stack[sp * TBLOCK + threadIdx.x] : M.spill[(long long)(sp - LDS_STACK) * M.spill_lanes];
+}
 
 __device__ __forceinline__ bool bvh_box(double lox, double loy, double loz, double hix, double hiy, double hiz, V3 o, V3 inv,
                                         double tlo, double thi, double& tnear) {
@@ -337,7 +346,6 @@ template <bool COUNT, class Sink, class E>
 __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, const Sink& sink,
                                              bool full_line, Work& w, E&& e) {
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
-    const int tid = threadIdx.x;
     int sp = 0;
     int cur = root;
     while (true) {
@@ -382,9 +390,9 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             cswap(tn[0], ch[0], tn[2], ch[2]);
             cswap(tn[1], ch[1], tn[3], ch[3]);
             cswap(tn[1], ch[1], tn[2], ch[2]);
-            if (ch[3] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[3];
-            if (ch[2] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[2];
-            if (ch[1] != INT32_MIN) M.stack[sp++ * TBLOCK + tid] = ch[1];
+            if (ch[3] != INT32_MIN) stack_push(M, sp++, ch[3]);
+            if (ch[2] != INT32_MIN) stack_push(M, sp++, ch[2]);
+            if (ch[1] != INT32_MIN) stack_push(M, sp++, ch[1]);
             if (ch[0] != INT32_MIN) { cur = ch[0]; continue; }
         } else {
             // ---- leaf: its (at most BVH_LEAF_MAX = 2) triangles arrive as one batch of loads
@@ -399,7 +407,7 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                                       [&](double tt, int k, double u, double v, int uv) { e(tt, tb.node * 4 + k, u, v, uv); });
         }
         if (sp == 0) break;
-        cur = M.stack[--sp * TBLOCK + tid];
+        cur = stack_pop(M, --sp);
     }
 }
 
@@ -562,15 +570,92 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     if (HAS_CSG) sink.flags |= cs->flags;
 }
 
-// Traversal kernels are persistent: a grid of as many 512-lane workgroups as fit the chip, each staging the BVH top
-// levels into LDS once and then walking chunks of TBLOCK rays (chunk c belongs to workgroup c % gridDim.x, so heavy
-// image regions are dealt round-robin over the CUs).  Dynamic LDS layout: [n_lds BvhNode][BVH_STACK x TBLOCK int].
-__device__ __forceinline__ TravMem trav_setup(const DScene& S) {
+// Chunk feed.  With a counter (`cnt` != null) the feed is dynamic and two-level: the WORKGROUP reserves a batch of
+// consecutive chunks from the global counter with one returning atomic (guided self-scheduling: batches shrink from 64
+// to 8 chunks as the queue drains, so the last batches are small), and its wavefronts take chunks out of the batch
+// with an LDS atomic on one packed word,  start << 24 | size << 16 | taken.  The wavefront that takes the slot just
+// past the batch refills it; the others poll the word (s_sleep between polls) until the batch changes.  No barrier:
+// a wavefront stuck on a heavy chunk never holds anyone up.  A batch that starts at or past n_chunks is the end
+// mark, and every wavefront reaches it.  One hot global word costs ~70 ns per returning atomic chip-wide, which is
+// why it is paid per batch and not per wavefront.  Without a counter: chunks are dealt round-robin over the
+// wavefronts of the grid.  Every value here is wavefront-uniform.
+struct Feed {
+    unsigned long long* cnt;
+    RT_LDS unsigned long long* state;
+    long long n_chunks;
+    long long next_static, stride_static;
+
+    __device__ __forceinline__ static unsigned long long reserve(unsigned long long* cnt, long long n_chunks) {
+        long long seen = (long long)__atomic_load_n(cnt, __ATOMIC_RELAXED);
+        long long size = (n_chunks - seen) / (2ll * gridDim.x);
+        size = size < 8 ? 8 : size > 64 ? 64 : size;
+        unsigned long long start = atomicAdd(cnt, (unsigned long long)size);
+        return (start << 24) | ((unsigned long long)size << 16);
+    }
+    // called by every thread of the workgroup before the setup barrier
+    __device__ __forceinline__ void init(unsigned long long* counter, long long chunks, RT_LDS unsigned long long* lds_word) {
+        cnt = counter;
+        state = lds_word;
+        n_chunks = chunks;
+        const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
+        next_static = wave;
+        stride_static = (long long)gridDim.x * (TBLOCK / 64);
+        if (cnt && threadIdx.x == 0) *state = reserve(cnt, n_chunks);
+    }
+    __device__ __forceinline__ static unsigned long long uniform(unsigned long long v) {
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    __device__ __forceinline__ long long next() {  // -1: nothing left
+        if (!cnt) {
+            long long c = next_static;
+            next_static += stride_static;
+            return c < n_chunks ? c : -1;
+        }
+        const bool leader = (threadIdx.x & 63) == 0;
+        while (true) {
+            unsigned long long v = 0;
+            if (leader) v = __hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            v = uniform(v);
+            const long long start = (long long)(v >> 24);
+            const int size = int((v >> 16) & 0xff), taken = int(v & 0xffff);
+            if (start >= n_chunks) return -1;
+            if (taken < size) {
+                if (start + taken < n_chunks) return start + taken;
+                continue;  // the tail of the last batch: keep taking until the refill slot comes up
+            }
+            if (taken == size) {  // refill
+                unsigned long long nv = 0;
+                if (leader) {
+                    nv = reserve(cnt, n_chunks);
+                    __hip_atomic_store(state, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                continue;
+            }
+            // somebody else is refilling
+            unsigned long long cur;
+            do {
+                __builtin_amdgcn_s_sleep(2);
+                cur = uniform(__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            } while ((long long)(cur >> 24) == start);
+        }
+    }
+};
+
+// Traversal kernels are persistent: a grid of as many 1024-lane workgroups as fit the chip, each staging the BVH
+// top levels into LDS once.  After that every WAVEFRONT works on its own: it pulls chunks of 64 rays from a feed
+// until the feed is dry, so a wavefront stuck on a heavy chunk never holds anyone else up.
+// Dynamic LDS layout: [n_lds BvhNode][LDS_STACK x TBLOCK int].
+__device__ __forceinline__ TravMem trav_setup(const DScene& S, Feed& feed, unsigned long long* feed_counter, long long n_chunks) {
     extern __shared__ __align__(16) unsigned char trav_lds[];
+    __shared__ unsigned long long feed_word;
+    feed.init(feed_counter, n_chunks, (RT_LDS unsigned long long*)&feed_word);
     TravMem M;
     M.n_lds = S.n_lds;
     M.lds_nodes = (const RT_LDS BvhNode*)trav_lds;
     M.stack = (RT_LDS int*)(trav_lds + (size_t)S.n_lds * sizeof(BvhNode));
+    M.spill_lanes = S.spill_lanes;
+    M.spill = S.spill + ((long long)blockIdx.x * TBLOCK + threadIdx.x) % S.spill_lanes;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(S.bvh);
     RT_LDS u32x4* dst = (RT_LDS u32x4*)trav_lds;
@@ -645,11 +730,11 @@ __global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long 
 
 template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n, unsigned long long* counters) {
-    const TravMem M = trav_setup(S);
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
     Work w = {};
-    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
-    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const long long i = c * TBLOCK + threadIdx.x;
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long i = c * 64 + (threadIdx.x & 63);
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         bool alive = false;
         if (i < n) {
@@ -971,12 +1056,12 @@ __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(
 
 template <bool HAS_CSG, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_shadow(DScene S, Level L, unsigned long long* counters) {
-    const TravMem M = trav_setup(S);
     const long long total = (long long)counters[CNT_SHADOW_Q] * S.n_lights;
-    const long long n_chunks = (total + TBLOCK - 1) / TBLOCK;
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_SHADOW, (total + 63) / 64);
     Work w = {};
-    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const long long j = c * TBLOCK + threadIdx.x;
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long j = c * 64 + (threadIdx.x & 63);
         const bool alive = j < total;
         int light = 0;
         long long i = 0;
@@ -998,12 +1083,12 @@ __global__ __launch_bounds__(TBLOCK) void k_shadow(DScene S, Level L, unsigned l
 
 template <bool HAS_CSG, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_container(DScene S, Level L, unsigned long long* counters) {
-    const TravMem M = trav_setup(S);
     const long long total = (long long)counters[CNT_CONTAINER_Q];
-    const long long n_chunks = (total + TBLOCK - 1) / TBLOCK;
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_CONTAINER, (total + 63) / 64);
     Work w = {};
-    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const long long j = c * TBLOCK + threadIdx.x;
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long j = c * 64 + (threadIdx.x & 63);
         const bool alive = j < total;
         long long i = 0;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
@@ -1202,10 +1287,10 @@ template <bool HAS_CSG>
 __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
                                                  const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
                                                  int32_t* id_out) {
-    const TravMem M = trav_setup(S);
-    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
-    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const long long i = c * TBLOCK + threadIdx.x;
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long i = c * 64 + (threadIdx.x & 63);
         const bool alive = i < n;
         double lt[LIST_CAP];
         int lk[LIST_CAP];
@@ -1232,10 +1317,10 @@ __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const do
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
 template <bool HAS_CSG>
 __global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
-    const TravMem M = trav_setup(S);
-    const long long n_chunks = (n + TBLOCK - 1) / TBLOCK;
-    for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const long long i = c * TBLOCK + threadIdx.x;
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long i = c * 64 + (threadIdx.x & 63);
         const bool alive = i < n;
         Work w = {};
         unsigned flags = 0;
