@@ -324,6 +324,14 @@ __device__ __forceinline__ bool bvh_box(double lox, double loy, double loz, doub
     return !(tmin > tmax + slack) && !(tmax < tlo - slack) && !(tmin > thi + slack);
 }
 
+// 1/d for the slab tests only (never for a reference formula): v_rcp_f64 plus one Newton step, ~1e-16 relative,
+// seven orders of magnitude inside the slab test's own slack; 1/0 stays +-inf and 1/inf stays 0.
+__device__ __forceinline__ double slab_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double r2 = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    return r2 == r2 ? r2 : r;
+}
+
 struct TriData {
     V3 p1, e1, e2;
     int node, smooth;
@@ -343,9 +351,8 @@ __device__ __forceinline__ void cswap(double& ta, int& ca, double& tb, int& cb) 
 }
 
 template <bool COUNT, class Sink, class E>
-__device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, const Sink& sink,
+__device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, V3 inv, const Sink& sink,
                                              bool full_line, Work& w, E&& e) {
-    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     int sp = 0;
     int cur = root;
     while (true) {
@@ -377,10 +384,9 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             double tn[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                double t;
-                bool hit = ch[c] != INT32_MIN &&
-                           bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
-                                   (double)hi[2][c], o, inv, tlo, thi, t);
+                double t;  // all four tests run unconditionally: no branch per child
+                bool hit = bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
+                                   (double)hi[2][c], o, inv, tlo, thi, t) & (ch[c] != INT32_MIN);
                 tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
                 if (!hit) ch[c] = INT32_MIN;
             }
@@ -547,7 +553,13 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         if (!on) continue;
         if (it.type == ITEM_MESH) {
             bool full_line = HAS_CSG && cs->depth > 0;  // a CSG filter needs its operands' hits behind the origin too
-            bvh_traverse<COUNT>(S, M, it.a, o, d, sink, full_line, w, out);
+            // the mesh's own (padded f64) box first: most rays of a frame never come near the mesh
+            const RT_CONSTANT double* __restrict__ mb = as_constant(S.mesh_box) + (size_t)it.b * 6;
+            const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+            double tnear;
+            bump<COUNT>(w.box);
+            if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo(), sink.hi(), tnear))
+                bvh_traverse<COUNT>(S, M, it.a, o, d, inv, sink, full_line, w, out);
             continue;
         }
         // ITEM_LEAF
@@ -570,37 +582,63 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     if (HAS_CSG) sink.flags |= cs->flags;
 }
 
-// Chunk feed.  With a counter (`cnt` != null) the feed is dynamic and two-level: the WORKGROUP reserves a batch of
-// consecutive chunks from the global counter with one returning atomic (guided self-scheduling: batches shrink from 64
-// to 8 chunks as the queue drains, so the last batches are small), and its wavefronts take chunks out of the batch
-// with an LDS atomic on one packed word,  start << 24 | size << 16 | taken.  The wavefront that takes the slot just
-// past the batch refills it; the others poll the word (s_sleep between polls) until the batch changes.  No barrier:
-// a wavefront stuck on a heavy chunk never holds anyone up.  A batch that starts at or past n_chunks is the end
-// mark, and every wavefront reaches it.  One hot global word costs ~70 ns per returning atomic chip-wide, which is
-// why it is paid per batch and not per wavefront.  Without a counter: chunks are dealt round-robin over the
-// wavefronts of the grid.  Every value here is wavefront-uniform.
+// Chunk feed.  With counters (`cnt` != null) the feed is dynamic and two-level.  The chunk range is cut into
+// FEED_PARTS equal partitions, each with its own counter on its own cache line (one hot word costs ~70 ns per
+// returning atomic chip-wide; eight lines take that off the critical path).  A WORKGROUP reserves a batch of
+// consecutive chunks from one partition with one returning atomic (guided self-scheduling: batches shrink from 64 to
+// 8 chunks as the partition drains; a workgroup starts on partition blockIdx % FEED_PARTS and moves on when that one
+// is dry), and its wavefronts take chunks out of the batch with an LDS atomic on one packed word,
+// start << 24 | size << 16 | taken.  The wavefront that takes the slot just past the batch refills it; the others
+// poll the word (s_sleep between polls) until the batch changes.  No barrier: a wavefront stuck on a heavy chunk
+// never holds anyone up.  A batch that starts at n_chunks is the end mark, and every wavefront reaches it.
+// Without counters: chunks are dealt round-robin over the wavefronts of the grid.  Values are wavefront-uniform.
+struct FeedShared {
+    unsigned long long word;  // start << 24 | size << 16 | taken
+    int part, dry;            // touched only by the wavefront that refills
+};
 struct Feed {
     unsigned long long* cnt;
-    RT_LDS unsigned long long* state;
+    RT_LDS FeedShared* sh;
     long long n_chunks;
     long long next_static, stride_static;
 
-    __device__ __forceinline__ static unsigned long long reserve(unsigned long long* cnt, long long n_chunks) {
-        long long seen = (long long)__atomic_load_n(cnt, __ATOMIC_RELAXED);
-        long long size = (n_chunks - seen) / (2ll * gridDim.x);
-        size = size < 8 ? 8 : size > 64 ? 64 : size;
-        unsigned long long start = atomicAdd(cnt, (unsigned long long)size);
-        return (start << 24) | ((unsigned long long)size << 16);
+    // one lane: next batch as a packed word, or the end mark
+    __device__ __forceinline__ unsigned long long reserve() {
+        const long long span = (n_chunks + FEED_PARTS - 1) / FEED_PARTS;
+        int part = sh->part, dry = sh->dry;
+        while (dry < FEED_PARTS) {
+            const long long lo = span * part, hi = lo + span < n_chunks ? lo + span : n_chunks;
+            unsigned long long* c = cnt + part * FEED_STRIDE;
+            const long long left = (hi - lo) - (long long)__atomic_load_n(c, __ATOMIC_RELAXED);
+            if (left > 0) {
+                long long size = left * FEED_PARTS / (2ll * gridDim.x);
+                size = size < 8 ? 8 : size > 64 ? 64 : size;
+                const long long start = lo + (long long)atomicAdd(c, (unsigned long long)size);
+                if (start < hi) {
+                    if (start + size > hi) size = hi - start;
+                    sh->part = part; sh->dry = dry;
+                    return ((unsigned long long)start << 24) | ((unsigned long long)size << 16);
+                }
+            }
+            part = (part + 1) % FEED_PARTS;
+            ++dry;
+        }
+        sh->part = part; sh->dry = dry;
+        return (unsigned long long)n_chunks << 24;
     }
     // called by every thread of the workgroup before the setup barrier
-    __device__ __forceinline__ void init(unsigned long long* counter, long long chunks, RT_LDS unsigned long long* lds_word) {
-        cnt = counter;
-        state = lds_word;
+    __device__ __forceinline__ void init(unsigned long long* counters, long long chunks, RT_LDS FeedShared* shared) {
+        cnt = counters;
+        sh = shared;
         n_chunks = chunks;
         const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
         next_static = wave;
         stride_static = (long long)gridDim.x * (TBLOCK / 64);
-        if (cnt && threadIdx.x == 0) *state = reserve(cnt, n_chunks);
+        if (cnt && threadIdx.x == 0) {
+            sh->part = int(blockIdx.x % FEED_PARTS);
+            sh->dry = 0;
+            sh->word = reserve();
+        }
     }
     __device__ __forceinline__ static unsigned long long uniform(unsigned long long v) {
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -615,20 +653,16 @@ struct Feed {
         const bool leader = (threadIdx.x & 63) == 0;
         while (true) {
             unsigned long long v = 0;
-            if (leader) v = __hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (leader) v = __hip_atomic_fetch_add(&sh->word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             v = uniform(v);
             const long long start = (long long)(v >> 24);
             const int size = int((v >> 16) & 0xff), taken = int(v & 0xffff);
             if (start >= n_chunks) return -1;
-            if (taken < size) {
-                if (start + taken < n_chunks) return start + taken;
-                continue;  // the tail of the last batch: keep taking until the refill slot comes up
-            }
+            if (taken < size) return start + taken;
             if (taken == size) {  // refill
-                unsigned long long nv = 0;
                 if (leader) {
-                    nv = reserve(cnt, n_chunks);
-                    __hip_atomic_store(state, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unsigned long long nv = reserve();
+                    __hip_atomic_store(&sh->word, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 continue;
             }
@@ -636,7 +670,7 @@ struct Feed {
             unsigned long long cur;
             do {
                 __builtin_amdgcn_s_sleep(2);
-                cur = uniform(__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                cur = uniform(__hip_atomic_load(&sh->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             } while ((long long)(cur >> 24) == start);
         }
     }
@@ -648,8 +682,8 @@ struct Feed {
 // Dynamic LDS layout: [n_lds BvhNode][LDS_STACK x TBLOCK int].
 __device__ __forceinline__ TravMem trav_setup(const DScene& S, Feed& feed, unsigned long long* feed_counter, long long n_chunks) {
     extern __shared__ __align__(16) unsigned char trav_lds[];
-    __shared__ unsigned long long feed_word;
-    feed.init(feed_counter, n_chunks, (RT_LDS unsigned long long*)&feed_word);
+    __shared__ FeedShared feed_shared;
+    feed.init(feed_counter, n_chunks, (RT_LDS FeedShared*)&feed_shared);
     TravMem M;
     M.n_lds = S.n_lds;
     M.lds_nodes = (const RT_LDS BvhNode*)trav_lds;

@@ -78,6 +78,7 @@ struct Compiler {
     std::vector<BvhNode> n4;
     std::vector<int32_t> n4_depth;
     std::vector<size_t> mesh_items;  // items whose `a` is a root index into n4
+    Box last_mesh_box;               // padded bounds of the mesh build_mesh built last
 
     int32_t emit_leaf(std::vector<TriRef>& refs, size_t lo, size_t hi) {
         int32_t first = int32_t(p.mesh_tris.size());
@@ -260,6 +261,7 @@ struct Compiler {
         n2.clear();
         Box rb;
         int32_t root = build(refs, 0, refs.size(), rb, 0);
+        last_mesh_box = rb;
         if (root < 0) {  // the whole mesh is one leaf: wrap it in a node
             Node2 nd;
             nd.box[0] = rb;
@@ -345,6 +347,9 @@ struct Compiler {
                 it.node = node;
                 set_chain(it, chain);
                 it.a = build_mesh(tris);
+                it.b = int32_t(p.mesh_box.size() / 6);
+                for (int k = 0; k < 3; ++k) p.mesh_box.push_back(last_mesh_box.lo[k]);
+                for (int k = 0; k < 3; ++k) p.mesh_box.push_back(last_mesh_box.hi[k]);
                 mesh_items.push_back(p.items.size());
                 p.items.push_back(it);
             }

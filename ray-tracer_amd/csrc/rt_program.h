@@ -32,7 +32,7 @@ struct Item {
     int32_t kind;       // ITEM_LEAF: RT_* kind of the node
     int32_t a;          // GATE: group box index; MESH: BVH root; CSG_END: first node of the left operand;
                         // LEAF triangle: triangle index
-    int32_t b;          // CSG_END: end of the left operand's node range
+    int32_t b;          // CSG_END: end of the left operand's node range;  MESH: index into mesh_box
     int32_t op;         // CSG_END: csg op;  LEAF cylinder / cone: closed
     int32_t chain_len;  // non-identity inverses to apply to the WORLD ray, outermost first
     int32_t x0, x1;     // the first two of them
@@ -69,6 +69,7 @@ struct Program {
                                        // (registry chain of src/shape.rs:394-420, identities kept)
     std::vector<BvhNode> bvh;
     std::vector<MeshTri> mesh_tris;
+    std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
     bool has_smooth = false;
     bool all_cast_shadow = true;

@@ -320,3 +320,64 @@ def test_instrumented_counters_do_not_change_the_image():
     assert wt[3] >= wt[4] + wt[5] + wt[6]
     traced = a.stats.rays_primary + a.stats.rays_reflect + a.stats.rays_refract
     assert wt[8] == traced and wt[7] == 2 * traced       # one plane and two spheres tested once per traced ray
+
+
+# ------------------------------------------------------------------ traversal machinery (non-semantic by design: prove it)
+def _stacked_triangles(n, dz):
+    g = Shape.group()
+    for k in range(n):
+        z = k * dz
+        g.add_child(Shape.triangle((-3. - 0.001 * k, -2., z), (3., -2. + 0.001 * k, z), (0., 3., z)))
+    return g
+
+
+def test_deep_traversal_spills_the_lds_stack():
+    # 3000 parallel triangles pierced by every camera ray: all four children of every BVH node are hit, so the
+    # per-lane stack runs past its LDS rows into the HBM spill rows; nearest hit and colours must not care
+    w = World()
+    w.lights.append(Light.point_light((-4, 6, -10), rt.WHITE))
+    w.objects.append(_stacked_triangles(3000, 0.002))
+    cam = Camera(24, 24, 0.5)
+    cam.transform = view_transform((0.2, 0.1, -8), (0, 0, 0), (0, 1, 0))
+    g, o = assert_image_parity(w, cam)
+    assert (g.hit_id > 0).sum() > 300
+    # full lists: more intersections than the device list holds is an error code, never a silent truncation
+    with pytest.raises(rt.RtError) as e:
+        w.intersect_world_batch(np.array([[0.2, 0.1, -8.]]), np.array([[0., 0., 1.]]), 64)
+    assert e.value.code == rt.RT_ERR_OVERFLOW
+
+
+def test_two_meshes_and_rays_that_miss_their_boxes():
+    # two triangle meshes under different transforms + rays that miss both mesh boxes entirely
+    w, cam = scenes.teapot_scene(64, 36)
+    teapot2, _ = rt.obj_to_group(scenes.read_asset("teapot.obj"))
+    teapot2.set_transform(translate(3.5, 0., 5.) * rotate(0.7, Axis.Y) * scale(0.6, 0.6, 0.6))
+    teapot2.set_material(Material(color=(0.2, 0.5, 0.9), reflective=0.2))
+    w.objects.append(teapot2)
+    assert_image_parity(w, cam)
+    o, d = _random_rays(800, 5, center=(4., 2., 2.), radius=30.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert (gc == 1).any() and (gc > 4).any()      # only the floor plane ... through to several mesh hits
+
+
+@pytest.mark.parametrize("index", [1.5, 0.0, -1.0, float("inf")])
+def test_glass_at_the_last_level(index):
+    # remaining == 0 at a transparent + reflective hit: the n1/n2 walk is skipped only when every refractive index is
+    # finite and positive; with a zero / negative / infinite index schlick can turn NaN or inf and the walk must run
+    w = World()
+    w.lights.append(Light.point_light((-5, 8, -6), rt.WHITE))
+    w.objects.append(Shape.sphere().set_material(Material(transparency=0.8, reflective=0.6, refractive_index=index, diffuse=0.2)))
+    w.objects.append(Shape.sphere().set_transform(scale(0.5, 0.5, 0.5)).set_material(Material(transparency=0.9, reflective=0.3, refractive_index=1.1)))
+    w.objects.append(Shape.plane().set_transform(translate(0, -1.5, 0)))
+    cam = Camera(40, 40, PI / 3)
+    cam.transform = view_transform((0, 1, -4), (0, 0, 0), (0, 1, 0))
+    for depth in (0, 1, 3):
+        g = cam.render(w, depth)
+        o = ob.render(w, cam, depth)
+        assert np.array_equal(g.hit_id, o.hit_id)
+        assert np.array_equal(np.isnan(g.rgb), np.isnan(o.rgb))
+        assert np.array_equal(np.isinf(g.rgb), np.isinf(o.rgb))
+        ok = np.isfinite(o.rgb)
+        assert float(np.abs(g.rgb[ok] - o.rgb[ok]).max(initial=0.)) < COLOR_TOL
