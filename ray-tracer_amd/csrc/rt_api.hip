@@ -192,15 +192,15 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
     return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
 }
 template <bool COUNT>
-int launch_shadow(rt_scene* s, hipStream_t st, const Level& L, long long n) {
-    const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1));  // the queue length lives on the device
-    if (s->has_csg) return launch_trav(s, st, k_shadow<true, COUNT>, upper, s->ds, L, s->d_counters);
-    return launch_trav(s, st, k_shadow<false, COUNT>, upper, s->ds, L, s->d_counters);
-}
-template <bool COUNT>
-int launch_container(rt_scene* s, hipStream_t st, const Level& L, long long n) {
-    if (s->has_csg) return launch_trav(s, st, k_container<true, COUNT>, chunks_for(n), s->ds, L, s->d_counters);
-    return launch_trav(s, st, k_container<false, COUNT>, chunks_for(n), s->ds, L, s->d_counters);
+int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases) {
+    // upper bound of the chunk count: the queue lengths live on the device
+    const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1)) + chunks_for(n);
+    if (s->has_csg) {
+        if (s->any_transparent) return launch_trav(s, st, k_secondary<true, COUNT, true>, upper, s->ds, L, s->d_counters, phases);
+        return launch_trav(s, st, k_secondary<true, COUNT, false>, upper, s->ds, L, s->d_counters, phases);
+    }
+    if (s->any_transparent) return launch_trav(s, st, k_secondary<false, COUNT, true>, upper, s->ds, L, s->d_counters, phases);
+    return launch_trav(s, st, k_secondary<false, COUNT, false>, upper, s->ds, L, s->d_counters, phases);
 }
 
 // color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
@@ -238,24 +238,27 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         tm.begin(stats ? &stats->ms_shade : nullptr);
         hipLaunchKernelGGL(k_prepare, g, b, 0, st, s->ds, L, n, remaining, s->d_counters);
         tm.end();
-        if (s->n_lights > 0) {
-            tm.begin(stats ? &stats->ms_shadow : nullptr);
-            { int rc = counters ? launch_shadow<true>(s, st, L, n) : launch_shadow<false>(s, st, L, n); if (rc != RT_OK) return rc; }
-            tm.end();
-            if (stats) stats->n_shadow_launches++;
-            if (counters && stats) {
+        const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
+        if (counters && stats) {  // instrumented run: one queue per launch, so that the work counters stay apart
+            for (int phase = 1; phase <= 2; phase <<= 1) {
+                if (!(want & phase)) continue;
+                tm.begin(phase == 1 ? &stats->ms_shadow : &stats->ms_collect);
+                { int rc = launch_secondary<true>(s, st, L, n, phase); if (rc != RT_OK) return rc; }
+                tm.end();
+                if (phase == 1) stats->n_shadow_launches++;
                 HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                int64_t* dst = phase == 1 ? stats->work_shadow : stats->work_container;
                 for (int k = 0; k < RT_WORK_COUNT; ++k) {
-                    stats->work_shadow[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
+                    dst[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
                     work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
                 }
             }
-        }
-        if (s->any_transparent) {
-            tm.begin(stats ? &stats->ms_collect : nullptr);
-            { int rc = counters ? launch_container<true>(s, st, L, n) : launch_container<false>(s, st, L, n); if (rc != RT_OK) return rc; }
+        } else if (want) {
+            tm.begin(stats ? &stats->ms_shadow : nullptr);
+            { int rc = counters ? launch_secondary<true>(s, st, L, n, want) : launch_secondary<false>(s, st, L, n, want); if (rc != RT_OK) return rc; }
             tm.end();
+            if (stats && (want & 1)) stats->n_shadow_launches++;
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
         hipLaunchKernelGGL(k_finish, g, b, 0, st, s->ds, L, N, n, remaining, next_cap, s->d_counters);
@@ -263,11 +266,6 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (counters && stats)
-            for (int k = 0; k < RT_WORK_COUNT; ++k) {
-                stats->work_container[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
-                work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
-            }
         counts.push_back(n);
         total_shaded += (long long)s->h_counters[CNT_SHADOW_Q];
         total_walks += (long long)s->h_counters[CNT_CONTAINER_Q];

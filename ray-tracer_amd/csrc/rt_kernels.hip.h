@@ -1088,15 +1088,54 @@ __global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long 
 __device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(point, vmul(normal, EPS)); }
 __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
 
-template <bool HAS_CSG, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_shadow(DScene S, Level L, unsigned long long* counters) {
-    const long long total = (long long)counters[CNT_SHADOW_Q] * S.n_lights;
-    Feed feed;
-    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_SHADOW, (total + 63) / 64);
+// One launch serves both queues of a level (`phases` bit 0: shadow queue, bit 1: container queue; the instrumented
+// run launches them one at a time to keep their work counters apart).  The container chunks — few, and each one a
+// long latency-bound walk — go first, so that they overlap the bulk of the shadow chunks instead of forming a tail.
+template <bool HAS_CSG, bool COUNT, bool WALK>
+__global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigned long long* counters, int phases) {
+    const long long n_shadow = (phases & 1) ? (long long)counters[CNT_SHADOW_Q] * S.n_lights : 0;
+    const long long n_walk = (WALK && (phases & 2)) ? (long long)counters[CNT_CONTAINER_Q] : 0;
+    Feed shadow_feed, walk_feed;
+    __shared__ FeedShared walk_shared;
+    walk_feed.init(counters + CNT_FEED_CONTAINER, (n_walk + 63) / 64, (RT_LDS FeedShared*)&walk_shared);
+    const TravMem M = trav_setup(S, shadow_feed, counters + CNT_FEED_SHADOW, (n_shadow + 63) / 64);
     Work w = {};
-    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+    if (WALK) {
+        for (long long c = walk_feed.next(); c >= 0; c = walk_feed.next()) {
+            const long long j = c * 64 + (threadIdx.x & 63);
+            const bool alive = j < n_walk;
+            long long i = 0;
+            V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+            double hit_t = 0.;
+            int hit_node = 0;
+            if (alive) {
+                i = L.cont_q[j];
+                o = mk(L.ox[i], L.oy[i], L.oz[i]);
+                d = mk(L.dx[i], L.dy[i], L.dz[i]);
+                hit_t = L.ht[i];
+                hit_node = L.hkey[i] >> 2;
+            }
+            unsigned flags = 0;
+            double n1, n2;
+            container_walk<HAS_CSG, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
+            if (alive) {
+                L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
+                L.hv[i] = n2;
+                {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish
+                    // can count its spawns before it does its work
+                    V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+                    double n_ratio = n1 / n2;
+                    double cos_i = dot(eye_vector, normal_vector);
+                    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                    if (sin2_t > 1.) L.mode[i] = 2;
+                }
+                if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
+            }
+        }
+    }
+    for (long long c = shadow_feed.next(); c >= 0; c = shadow_feed.next()) {
         const long long j = c * 64 + (threadIdx.x & 63);
-        const bool alive = j < total;
+        const bool alive = j < n_shadow;
         int light = 0;
         long long i = 0;
         V3 over_point = mk(0., 0., 0.);
@@ -1109,46 +1148,6 @@ __global__ __launch_bounds__(TBLOCK) void k_shadow(DScene S, Level L, unsigned l
         bool sh = is_shadowed<HAS_CSG, COUNT>(S, M, over_point, light, w, flags, alive);
         if (alive) {
             L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
-            if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
-        }
-    }
-    if (COUNT) flush_work(w, counters);
-}
-
-template <bool HAS_CSG, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_container(DScene S, Level L, unsigned long long* counters) {
-    const long long total = (long long)counters[CNT_CONTAINER_Q];
-    Feed feed;
-    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_CONTAINER, (total + 63) / 64);
-    Work w = {};
-    for (long long c = feed.next(); c >= 0; c = feed.next()) {
-        const long long j = c * 64 + (threadIdx.x & 63);
-        const bool alive = j < total;
-        long long i = 0;
-        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        double hit_t = 0.;
-        int hit_node = 0;
-        if (alive) {
-            i = L.cont_q[j];
-            o = mk(L.ox[i], L.oy[i], L.oz[i]);
-            d = mk(L.dx[i], L.dy[i], L.dz[i]);
-            hit_t = L.ht[i];
-            hit_node = L.hkey[i] >> 2;
-        }
-        unsigned flags = 0;
-        double n1, n2;
-        container_walk<HAS_CSG, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
-        if (alive) {
-            L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
-            L.hv[i] = n2;
-            {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish can
-                // count its spawns before it does its work
-                V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-                double n_ratio = n1 / n2;
-                double cos_i = dot(eye_vector, normal_vector);
-                double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                if (sin2_t > 1.) L.mode[i] = 2;
-            }
             if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
         }
     }
