@@ -35,7 +35,7 @@ F_LIGHTING = 75       # Material::lighting per light (+ one powf)
 F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
 B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
 # bytes of level state read + written per ray by each stage (rt_device.h: Level columns touched)
-B_RAY_IO = {"k_trace": 48 + 29, "shadow": 4 + 48 + 1, "container": 4 + 64 + 16, "k_prepare+k_finish": 2 * 150}
+B_RAY_IO = {"k_trace": 48 + 17, "k_trace_hit": 56, "shadow": 4 + 48 + 1, "container": 4 + 64 + 16 + 4, "k_queue+k_finish": 4 + 16 + 150}
 
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
@@ -170,16 +170,17 @@ def main():
         # run counts the two queues' work apart (sc.work_shadow / sc.work_container), the timed runs launch them together
         w_sec = [a + b for a, b in zip(sc.work_shadow, sc.work_container)]
         works = {"k_trace": list(sc.work_trace), "k_secondary": w_sec}
-        ms = {"k_trace": ev["ms_trace"], "k_secondary": ev["ms_shadow"] + ev["ms_collect"], "k_prepare+k_finish": ev["ms_shade"]}
+        ms = {"k_trace": ev["ms_trace"], "k_secondary": ev["ms_shadow"] + ev["ms_collect"], "k_queue+k_finish": ev["ms_shade"]}
         launches = {"k_trace": st.n_trace_launches, "k_secondary": st.n_shadow_launches,
-                    "k_prepare+k_finish": 2 * st.n_trace_launches}
+                    "k_queue+k_finish": 2 * st.n_trace_launches}
         traced = st.rays_primary + st.rays_reflect + st.rays_refract
         flops = {k: work_flops(v) for k, v in works.items()}
-        flops["k_prepare+k_finish"] = st.shaded_nodes * (F_PREPARE + F_LIGHTING * n_lights) + st.rays_reflect * F_REFLECT + \
+        flops["k_trace"] += st.shaded_nodes * F_PREPARE   # prepare_computations runs in k_trace's epilogue
+        flops["k_queue+k_finish"] = st.shaded_nodes * F_LIGHTING * n_lights + st.rays_reflect * F_REFLECT + \
             st.rays_refract * (F_REFRACT + F_SCHLICK)
-        nbytes = {"k_trace": work_bytes(works["k_trace"]) + traced * B_RAY_IO["k_trace"],
+        nbytes = {"k_trace": work_bytes(works["k_trace"]) + traced * B_RAY_IO["k_trace"] + st.shaded_nodes * B_RAY_IO["k_trace_hit"],
                   "k_secondary": work_bytes(w_sec) + st.rays_shadow * B_RAY_IO["shadow"] + st.rays_container * B_RAY_IO["container"],
-                  "k_prepare+k_finish": traced * B_RAY_IO["k_prepare+k_finish"]}
+                  "k_queue+k_finish": traced * B_RAY_IO["k_queue+k_finish"]}
         dom = max(("k_trace", "k_secondary"), key=lambda k: ms[k])
         n_launch = max(launches[dom], 1)
         pmc = None

@@ -183,13 +183,13 @@ int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... 
 inline long long chunks_for(long long n) { return (n + TBLOCK - 1) / TBLOCK; }
 
 template <bool COUNT>
-int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n) {
+int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, int remaining) {
     if (s->has_csg) {
-        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
-        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
+        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
+        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
     }
-    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
-    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, s->d_counters);
+    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
+    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
 }
 template <bool COUNT>
 int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases) {
@@ -223,7 +223,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
         HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, (CNT_TOTAL - CNT_NEXT) * sizeof(unsigned long long), st));
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        { int rc = counters ? launch_trace<true>(s, st, L, n) : launch_trace<false>(s, st, L, n); if (rc != RT_OK) return rc; }
+        { int rc = counters ? launch_trace<true>(s, st, L, n, remaining) : launch_trace<false>(s, st, L, n, remaining); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
         if (counters && stats) {  // instrumented run: split the work counters per kernel class
@@ -234,9 +234,8 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
                 work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
             }
         }
-        dim3 g(unsigned((n + TILE - 1) / TILE)), b(BLOCK);
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_prepare, g, b, 0, st, s->ds, L, n, remaining, s->d_counters);
+        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, next_cap, s->d_counters);
         tm.end();
         const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
         if (counters && stats) {  // instrumented run: one queue per launch, so that the work counters stay apart
@@ -261,7 +260,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
             if (stats && (want & 1)) stats->n_shadow_launches++;
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_finish, g, b, 0, st, s->ds, L, N, n, remaining, next_cap, s->d_counters);
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, remaining);
         tm.end();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -289,7 +288,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
     if (stats) {
         const unsigned long long* c = s->h_counters;
         stats->rays_reflect = (int64_t)c[CNT_REFLECT];
-        stats->rays_refract = (int64_t)c[CNT_REFRACT];
+        stats->rays_refract = (int64_t)c[CNT_REFRACT] - (int64_t)c[CNT_TIR];
         stats->shaded_nodes = total_shaded;
         stats->rays_shadow = total_shaded * s->n_lights;
         stats->rays_container = total_walks;

@@ -86,6 +86,7 @@ enum Counter : int {
     CNT_REFRACT,       // refraction rays spawned
     CNT_SHADED,        // nodes that hit something
     CNT_CONTAINER,     // container-walk list passes
+    CNT_TIR,           // refraction slots reserved by k_queue that total internal reflection left dead
     CNT_W_XFORMS,
     CNT_W_BOX,
     CNT_W_GATE,

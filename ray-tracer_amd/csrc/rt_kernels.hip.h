@@ -760,46 +760,6 @@ __global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Kernel: closest hit for one level == intersect_world + Intersection::hit (+ which u,v normal_at will see).
-
-template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n, unsigned long long* counters) {
-    Feed feed;
-    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
-    Work w = {};
-    for (long long c = feed.next(); c >= 0; c = feed.next()) {
-        const long long i = c * 64 + (threadIdx.x & 63);
-        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        bool alive = false;
-        if (i < n) {
-            o = mk(L.ox[i], L.oy[i], L.oz[i]);
-            d = mk(L.dx[i], L.dy[i], L.dz[i]);
-            alive = o.x == o.x;  // NaN origin = padding slot
-        }
-        ClosestSink<NEED_FIRST> sink;
-        sink.init(INFINITY);
-        traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
-        if (i < n) {
-            if (alive) {
-                double u = sink.bu, v = sink.bv;
-                unsigned flags = sink.flags;
-                if (NEED_FIRST && sink.best_key >= 0 && S.node_kind[sink.best_key >> 2] == RT_SMOOTH_TRIANGLE) {
-                    if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
-                    else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
-                }
-                L.ht[i] = sink.best_t; L.hu[i] = u; L.hv[i] = v;
-                L.hkey[i] = sink.best_key;
-                L.flags[i] = (uint8_t)flags;
-            } else {
-                L.hkey[i] = -1;
-                L.flags[i] = 0;
-            }
-        }
-    }
-    if (COUNT) flush_work(w, counters);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Shading: prepare_computations, is_shadowed, lighting, ray spawn.
 
 // Shape::normal_at (src/shape.rs:92-108): world_to_object down the registry chain, local normal, normal_to_world up.
@@ -993,28 +953,25 @@ __device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Shading of one level as four wavefront stages (each launch is dense: no lane idles through someone else's
-// traversal):
-//   k_prepare   prepare_computations for every hit; queues the hit for the shadow stage and, when its material
-//               is transparent, for the container stage (ballot-compacted queues, one atomic per wavefront)
-//   k_shadow    World::is_shadowed for every queued (hit, light)
-//   k_container the n1/n2 walk for every queued transparent hit
-//   k_finish    Material::lighting over the lights, reflected_color / refracted_color ray spawn, node record
-// Between k_prepare and k_finish the world-space point and normal live in the (not yet written) surface /
-// coefficient columns of the level, and n1/n2 in the hit-u/v columns prepare has finished reading.
+// One recursion level = four launches:
+//   k_trace      closest hit (intersect_world + Intersection::hit) and, in the same lane while ray and hit are in
+//                registers, prepare_computations (point, normal chain, inside flip) + the per-ray stage bits
+//   k_queue      pure stream compaction over the stage bits: shadow queue, container queue and the slots of the
+//                reflection / refraction rays in level d+1 (tile-counted, a handful of atomics per 8192 rays)
+//   k_secondary  World::is_shadowed for every queued (hit, light) and the n1/n2 walk for every queued transparent hit
+//   k_finish     Material::lighting over the lights, reflected_color / refracted_color ray spawn into the slots,
+//                node record; one ray per lane, no atomics, no barriers
+// Between k_trace and k_finish the world-space point and normal live in the (not yet written) surface / coefficient
+// columns of the level, and n1/n2 in the hit-u/v columns.
+//
+// Stage bits (Level::mode until k_finish overwrites it with the Schlick flag):
+constexpr int ST_HIT = 1;        // the ray hit something: shade it
+constexpr int ST_WALK = 2;       // prepare_computations' n1/n2 are observable for this hit: run the container walk
+constexpr int ST_REFLECT = 4;    // reflected_color spawns a ray (src/world.rs:110)
+constexpr int ST_REFRACT = 8;    // refracted_color gets past its first test (src/world.rs:121); a slot is reserved
+constexpr int ST_TIR = 16;       // ... but total internal reflection (src/world.rs:128): the slot stays a dead ray
 
 __device__ __forceinline__ unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
-
-// Queue appends without an atomic per wavefront (one returning atomic on one word saturates near 90 per
-// microsecond chip-wide, which at 100k wavefronts per frame costs more than the shading itself): a workgroup owns
-// a TILE of TILE_ITERS x BLOCK consecutive rays, counts its appends in a cheap first pass, reserves its slots with
-// ONE atomic per queue, then does the work in a second pass with slots known.
-constexpr int TILE_ITERS = 8;
-constexpr int TILE = TILE_ITERS * BLOCK;
-struct TileSlots {
-    int off[2][TILE_ITERS][BLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
-    long long base[2];
-};
 
 __device__ __forceinline__ bool needs_walk(const DScene& S, const double* __restrict__ m, int remaining) {
     // n1/n2 are read only by refracted_color and schlick, both behind a transparency test.  At remaining <= 0
@@ -1026,61 +983,123 @@ __device__ __forceinline__ bool needs_walk(const DScene& S, const double* __rest
     return !near_eq(m[RT_MAT_TRANSPARENCY], 0.) || (m[RT_MAT_REFLECTIVE] > 0. && m[RT_MAT_TRANSPARENCY] > 0.);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_prepare(DScene S, Level L, long long n, int remaining, unsigned long long* counters) {
+// `remaining` is the value color_at was called with at this level.
+template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
+__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n, int remaining, unsigned long long* counters) {
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
+    Work w = {};
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long i = c * 64 + (threadIdx.x & 63);
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        bool alive = false;
+        if (i < n) {
+            o = mk(L.ox[i], L.oy[i], L.oz[i]);
+            d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            alive = o.x == o.x;  // NaN origin = padding slot / dead ray
+        }
+        ClosestSink<NEED_FIRST> sink;
+        sink.init(INFINITY);
+        traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
+        if (i >= n) continue;
+        int stage = 0;
+        unsigned flags = 0;
+        const int key = alive ? sink.best_key : -1;
+        if (key >= 0) {
+            const int node = key >> 2;
+            const int kind = S.node_kind[node];
+            double u = sink.bu, v = sink.bv;
+            flags = sink.flags;
+            if (NEED_FIRST && kind == RT_SMOOTH_TRIANGLE) {
+                if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+                else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+            }
+            // prepare_computations, src/intersection.rs:38-48
+            V3 point = vadd(o, vmul(d, sink.best_t));  // Ray::position
+            V3 local_point = world_to_object(S, node, point);
+            V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, u, v));
+            V3 eye_vector = vneg(d);
+            if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
+            L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
+            L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
+            L.ht[i] = sink.best_t;
+            const double* __restrict__ m = S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE;
+            stage = ST_HIT;
+            if (needs_walk(S, m, remaining)) stage |= ST_WALK;
+            if (!(near_eq(m[RT_MAT_REFLECTIVE], 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
+            if (!(near_eq(m[RT_MAT_TRANSPARENCY], 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
+        }
+        L.hkey[i] = key;
+        L.mode[i] = stage;
+        L.flags[i] = (uint8_t)flags;
+    }
+    if (COUNT) flush_work(w, counters);
+}
+
+// Queue appends without an atomic per wavefront (returning atomics on one word are serialised in L2, 5-10 ns each
+// chip-wide): a workgroup owns a TILE of consecutive rays, counts its appends in a first pass over the stage bits,
+// reserves its slots with ONE atomic per queue, then writes the entries in a second pass with slots known.
+constexpr int TILE_ITERS = 32;
+constexpr int TILE = TILE_ITERS * BLOCK;
+struct TileSlots {
+    int off[4][TILE_ITERS][BLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
+    long long base[3];                   // shadow queue, container queue, next level
+};
+
+__global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n, long long next_cap, unsigned long long* counters) {
     __shared__ TileSlots ts;
     const long long tile0 = (long long)blockIdx.x * TILE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // ---- pass 1: who goes to the shadow queue (every hit) and to the container queue (transparent hits)
-    for (int it = 0; it < TILE_ITERS; ++it) {
+    int stage[TILE_ITERS];
+#pragma unroll
+    for (int it = 0; it < TILE_ITERS; ++it) {  // independent coalesced loads, all in flight together
         long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
-        bool shaded = false, walk = false;
-        if (i < n) {
-            int key = L.hkey[i];
-            if (key >= 0) {
-                shaded = true;
-                walk = needs_walk(S, S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE, remaining);
-            }
+        stage[it] = i < n ? L.mode[i] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < TILE_ITERS; ++it) {
+        unsigned long long b0 = __ballot(stage[it] & ST_HIT), b1 = __ballot(stage[it] & ST_WALK);
+        unsigned long long b2 = __ballot(stage[it] & ST_REFLECT), b3 = __ballot(stage[it] & ST_REFRACT);
+        if (lane == 0) {
+            ts.off[0][it][wave] = __popcll(b0); ts.off[1][it][wave] = __popcll(b1);
+            ts.off[2][it][wave] = __popcll(b2); ts.off[3][it][wave] = __popcll(b3);
         }
-        unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
-        if (lane == 0) { ts.off[0][it][wave] = __popcll(bs); ts.off[1][it][wave] = __popcll(bw); }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 2) {  // shadow queue, container queue
         const int q = threadIdx.x;
         int run = 0;
         for (int it = 0; it < TILE_ITERS; ++it)
             for (int w = 0; w < BLOCK / 64; ++w) { int c = ts.off[q][it][w]; ts.off[q][it][w] = run; run += c; }
         ts.base[q] = run ? (long long)atomicAdd(counters + (q == 0 ? CNT_SHADOW_Q : CNT_CONTAINER_Q), (unsigned long long)run) : 0;
+    } else if (threadIdx.x == 64) {  // both ray kinds share the next level's queue: reflection rays of a wavefront first
+        int run = 0, n_refl = 0, n_refr = 0;
+        for (int it = 0; it < TILE_ITERS; ++it)
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                int c0 = ts.off[2][it][w], c1 = ts.off[3][it][w];
+                ts.off[2][it][w] = run; run += c0;
+                ts.off[3][it][w] = run; run += c1;
+                n_refl += c0; n_refr += c1;
+            }
+        ts.base[2] = run ? (long long)atomicAdd(counters + CNT_NEXT, (unsigned long long)run) : 0;
+        if (n_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)n_refl);
+        if (n_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)n_refr);
     }
     __syncthreads();
-    // ---- pass 2: prepare_computations
+#pragma unroll
     for (int it = 0; it < TILE_ITERS; ++it) {
         long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
-        bool shaded = false, walk = false;
+        const int st = stage[it];
+        unsigned long long b0 = __ballot(st & ST_HIT), b1 = __ballot(st & ST_WALK);
+        unsigned long long b2 = __ballot(st & ST_REFLECT), b3 = __ballot(st & ST_REFRACT);
+        if (st & ST_HIT) L.shadow_q[ts.base[0] + ts.off[0][it][wave] + __popcll(b0 & lanes_below())] = (int32_t)i;
+        if (st & ST_WALK) L.cont_q[ts.base[1] + ts.off[1][it][wave] + __popcll(b1 & lanes_below())] = (int32_t)i;
         if (i < n) {
-            int key = L.hkey[i];
-            L.child_refl[i] = -1;
-            L.child_refr[i] = -1;
-            L.mode[i] = 0;
-            if (key >= 0) {
-                shaded = true;
-                const int node = key >> 2;
-                const int kind = S.node_kind[node];
-                V3 o = mk(L.ox[i], L.oy[i], L.oz[i]), d = mk(L.dx[i], L.dy[i], L.dz[i]);
-                // src/intersection.rs:38-48
-                V3 point = vadd(o, vmul(d, L.ht[i]));  // Ray::position
-                V3 local_point = world_to_object(S, node, point);
-                V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, L.hu[i], L.hv[i]));
-                V3 eye_vector = vneg(d);
-                if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
-                L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
-                L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
-                walk = needs_walk(S, S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE, remaining);
-            }
+            long long s0 = ts.base[2] + ts.off[2][it][wave] + __popcll(b2 & lanes_below());
+            long long s1 = ts.base[2] + ts.off[3][it][wave] + __popcll(b3 & lanes_below());
+            L.child_refl[i] = (st & ST_REFLECT) && s0 < next_cap ? (int)s0 : -1;
+            L.child_refr[i] = (st & ST_REFRACT) && s1 < next_cap ? (int)s1 : -1;
         }
-        unsigned long long bs = __ballot(shaded), bw = __ballot(walk);
-        if (shaded) L.shadow_q[ts.base[0] + ts.off[0][it][wave] + __popcll(bs & lanes_below())] = (int32_t)i;
-        if (walk) L.cont_q[ts.base[1] + ts.off[1][it][wave] + __popcll(bw & lanes_below())] = (int32_t)i;
     }
 }
 
@@ -1117,6 +1136,7 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
             }
             unsigned flags = 0;
             double n1, n2;
+            bool tir = false;
             container_walk<HAS_CSG, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
             if (alive) {
                 L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
@@ -1127,10 +1147,13 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
                     double n_ratio = n1 / n2;
                     double cos_i = dot(eye_vector, normal_vector);
                     double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                    if (sin2_t > 1.) L.mode[i] = 2;
+                    tir = sin2_t > 1. && (L.mode[i] & ST_REFRACT);
+                    if (tir) L.mode[i] |= ST_TIR;
                 }
                 if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
             }
+            const unsigned long long bt = __ballot(tir);  // refraction rays k_queue counted that will never fly
+            if (bt && (threadIdx.x & 63) == 0) atomicAdd(counters + CNT_TIR, (unsigned long long)__popcll(bt));
         }
     }
     for (long long c = shadow_feed.next(); c >= 0; c = shadow_feed.next()) {
@@ -1154,108 +1177,55 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
     if (COUNT) flush_work(w, counters);
 }
 
-// `remaining` is the value color_at was called with at this level.
-__device__ __forceinline__ void spawn_wishes(const double* __restrict__ m, int mode_bits, int remaining, bool& refl, bool& refr) {
-    refl = !(near_eq(m[RT_MAT_REFLECTIVE], 0.) || remaining <= 0);                            // src/world.rs:110
-    refr = !(near_eq(m[RT_MAT_TRANSPARENCY], 0.) || remaining <= 0) && !(mode_bits & 2);      // src/world.rs:121,128
-}
-
-__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n, int remaining, long long next_cap,
-                                                   unsigned long long* counters) {
-    __shared__ TileSlots ts;
-    const long long tile0 = (long long)blockIdx.x * TILE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // ---- pass 1: count the reflection and refraction rays this tile will spawn
-    for (int it = 0; it < TILE_ITERS; ++it) {
-        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
-        bool want_refl = false, want_refr = false;
-        if (i < n) {
-            int key = L.hkey[i];
-            if (key >= 0) spawn_wishes(S.mat + (size_t)S.node_material[key >> 2] * RT_MAT_STRIDE, L.mode[i], remaining, want_refl, want_refr);
-        }
-        unsigned long long b0 = __ballot(want_refl), b1 = __ballot(want_refr);
-        if (lane == 0) { ts.off[0][it][wave] = __popcll(b0); ts.off[1][it][wave] = __popcll(b1); }
+__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n, int remaining) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int stage = L.mode[i];
+    if (!(stage & ST_HIT)) return;
+    const int node = L.hkey[i] >> 2;
+    V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
+    V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+    V3 eye_vector = vneg(d);
+    V3 over_point = over_point_of(point, normal_vector);
+    const int mi = S.node_material[node];
+    const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
+    const int pat = S.mat_pattern[mi];
+    const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
+    const bool walked = stage & ST_WALK;
+    const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
+    // src/world.rs:57-66
+    V3 surface = mk(0., 0., 0.);
+    for (int l = 0; l < S.n_lights; ++l)
+        surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector, L.shadowed[i * S.n_lights + l] != 0));
+    const int c0 = L.child_refl[i], c1 = L.child_refr[i];
+    if (c0 >= 0) {  // reflected_color, src/world.rs:109-118
+        V3 refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
+        N.ox[c0] = over_point.x; N.oy[c0] = over_point.y; N.oz[c0] = over_point.z;
+        N.dx[c0] = refl_d.x; N.dy[c0] = refl_d.y; N.dz[c0] = refl_d.z;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // both kinds share the next level's queue: reflection rays of a wavefront first
-        int run = 0, n_refl = 0, n_refr = 0;
-        for (int it = 0; it < TILE_ITERS; ++it)
-            for (int w = 0; w < BLOCK / 64; ++w) {
-                int c0 = ts.off[0][it][w], c1 = ts.off[1][it][w];
-                ts.off[0][it][w] = run; run += c0;
-                ts.off[1][it][w] = run; run += c1;
-                n_refl += c0; n_refr += c1;
-            }
-        ts.base[0] = run ? (long long)atomicAdd(counters + CNT_NEXT, (unsigned long long)run) : 0;
-        if (n_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)n_refl);
-        if (n_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)n_refr);
-    }
-    __syncthreads();
-    // ---- pass 2: shade_hit
-    for (int it = 0; it < TILE_ITERS; ++it) {
-        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
-        bool want_refl = false, want_refr = false;
-        V3 refl_o = mk(0, 0, 0), refl_d = mk(0, 0, 0), refr_o = mk(0, 0, 0), refr_d = mk(0, 0, 0);
-        if (i < n) {
-            int key = L.hkey[i];
-            if (key >= 0) {
-                const int node = key >> 2;
-                V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
-                V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-                V3 eye_vector = vneg(d);
-                V3 over_point = over_point_of(point, normal_vector);
-                const int mi = S.node_material[node];
-                const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
-                const int pat = S.mat_pattern[mi];
-                const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
-                const bool walked = needs_walk(S, m, remaining);
-                const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
-                spawn_wishes(m, L.mode[i], remaining, want_refl, want_refr);
-                // src/world.rs:57-66
-                V3 surface = mk(0., 0., 0.);
-                for (int l = 0; l < S.n_lights; ++l)
-                    surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector,
-                                                     L.shadowed[i * S.n_lights + l] != 0));
-                if (want_refl) {  // reflected_color, src/world.rs:109-118
-                    refl_o = over_point;
-                    refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
-                }
-                if (want_refr) {  // refracted_color, src/world.rs:120-137 (sin2_t <= 1 established by k_container)
-                    double n_ratio = n1 / n2;
-                    double cos_i = dot(eye_vector, normal_vector);
-                    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                    double cos_t = sqrt(1. - sin2_t);
-                    refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
-                    refr_o = under_point_of(point, normal_vector);
-                }
-                int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
-                double reflectance = mode && walked ? schlick(eye_vector, normal_vector, n1, n2) : 0.;  // see needs_walk
-                // the point / normal columns are dead from here on: they become the node record
-                L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
-                L.k_refl[i] = reflective;
-                L.k_transp[i] = transparency;
-                L.k_schlick[i] = reflectance;
-                L.mode[i] = mode;
-            }
-        }
-        unsigned long long b0 = __ballot(want_refl), b1 = __ballot(want_refr);
-        if (want_refl) {
-            long long s = ts.base[0] + ts.off[0][it][wave] + __popcll(b0 & lanes_below());
-            if (s < next_cap) {
-                N.ox[s] = refl_o.x; N.oy[s] = refl_o.y; N.oz[s] = refl_o.z;
-                N.dx[s] = refl_d.x; N.dy[s] = refl_d.y; N.dz[s] = refl_d.z;
-                L.child_refl[i] = (int)s;
-            }
-        }
-        if (want_refr) {
-            long long s = ts.base[0] + ts.off[1][it][wave] + __popcll(b1 & lanes_below());
-            if (s < next_cap) {
-                N.ox[s] = refr_o.x; N.oy[s] = refr_o.y; N.oz[s] = refr_o.z;
-                N.dx[s] = refr_d.x; N.dy[s] = refr_d.y; N.dz[s] = refr_d.z;
-                L.child_refr[i] = (int)s;
-            }
+    if (c1 >= 0) {
+        if (stage & ST_TIR) {  // refracted_color returns BLACK (src/world.rs:128-130): the reserved slot is a dead ray
+            N.ox[c1] = NAN;
+            L.child_refr[i] = -1;
+        } else {  // refracted_color, src/world.rs:120-137
+            double n_ratio = n1 / n2;
+            double cos_i = dot(eye_vector, normal_vector);
+            double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+            double cos_t = sqrt(1. - sin2_t);
+            V3 refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
+            V3 refr_o = under_point_of(point, normal_vector);
+            N.ox[c1] = refr_o.x; N.oy[c1] = refr_o.y; N.oz[c1] = refr_o.z;
+            N.dx[c1] = refr_d.x; N.dy[c1] = refr_d.y; N.dz[c1] = refr_d.z;
         }
     }
+    int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
+    double reflectance = mode && walked ? schlick(eye_vector, normal_vector, n1, n2) : 0.;  // see needs_walk
+    // the point / normal columns are dead from here on: they become the node record
+    L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
+    L.k_refl[i] = reflective;
+    L.k_transp[i] = transparency;
+    L.k_schlick[i] = reflectance;
+    L.mode[i] = mode;
 }
 
 // Kernel: bottom-up resolve of one level == the tail of shade_hit (src/world.rs:68-78) + color_at's miss case.
