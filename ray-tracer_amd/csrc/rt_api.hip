@@ -183,28 +183,87 @@ int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... 
 inline long long chunks_for(long long n) { return (n + TBLOCK - 1) / TBLOCK; }
 
 template <bool COUNT>
-int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, int remaining) {
+int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, int remaining,
+                 unsigned long long* ctr) {
     if (s->has_csg) {
-        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
-        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
+        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
+        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
     }
-    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
-    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, remaining, s->d_counters);
+    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
+    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
 }
 template <bool COUNT>
-int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases) {
+int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases, unsigned long long* ctr) {
     // upper bound of the chunk count: the queue lengths live on the device
     const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1)) + chunks_for(n);
     if (s->has_csg) {
-        if (s->any_transparent) return launch_trav(s, st, k_secondary<true, COUNT, true>, upper, s->ds, L, s->d_counters, phases);
-        return launch_trav(s, st, k_secondary<true, COUNT, false>, upper, s->ds, L, s->d_counters, phases);
+        if (s->any_transparent) return launch_trav(s, st, k_secondary<true, COUNT, true>, upper, s->ds, L, ctr, phases);
+        return launch_trav(s, st, k_secondary<true, COUNT, false>, upper, s->ds, L, ctr, phases);
     }
-    if (s->any_transparent) return launch_trav(s, st, k_secondary<false, COUNT, true>, upper, s->ds, L, s->d_counters, phases);
-    return launch_trav(s, st, k_secondary<false, COUNT, false>, upper, s->ds, L, s->d_counters, phases);
+    if (s->any_transparent) return launch_trav(s, st, k_secondary<false, COUNT, true>, upper, s->ds, L, ctr, phases);
+    return launch_trav(s, st, k_secondary<false, COUNT, false>, upper, s->ds, L, ctr, phases);
 }
+
+// Maximum number of recursion levels a frame can be enqueued for without a host round trip per level
+// (one counter block per level).
+constexpr int ASYNC_LEVELS = 34;
+
+// The whole frame in one go: every level's launches are enqueued back to back, each level reads its ray count from
+// the counter block of the level before it, and the host waits once, at the end.  Possible when the per-level
+// queues already exist (a synchronous frame has sized them); if a level spawned more rays than its queue holds —
+// the view changed — nothing was written out of bounds and the caller falls back to the synchronous walk, which
+// grows the queues.  Returns RT_OK with *overflow set in that case.
+int run_levels_async(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool* overflow) {
+    const int D = max_depth;
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, size_t(D + 1) * CNT_TOTAL * sizeof(unsigned long long), st));
+    const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
+    for (int d = 0; d <= D; ++d) {
+        const int remaining = D - d;
+        const Level& L = s->levels[size_t(d)].L;
+        const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
+        const long long n = d == 0 ? n0 : s->levels[size_t(d)].cap;
+        const long long next_cap = remaining > 0 ? s->levels[size_t(d) + 1].cap : 0;
+        unsigned long long* ctr = s->d_counters + size_t(d) * CNT_TOTAL;
+        const unsigned long long* n_dev = d == 0 ? nullptr : s->d_counters + size_t(d - 1) * CNT_TOTAL + CNT_NEXT;
+        int rc = launch_trace<false>(s, st, L, n, n_dev, remaining, ctr);
+        if (rc != RT_OK) return rc;
+        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+        if (want) {
+            rc = launch_secondary<false>(s, st, L, n, want, ctr);
+            if (rc != RT_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, n_dev, remaining);
+    }
+    for (int d = D; d >= 0; --d) {
+        const Level& L = s->levels[size_t(d)].L;
+        const Level& N = d < D ? s->levels[size_t(d) + 1].L : L;
+        const long long n = d == 0 ? n0 : s->levels[size_t(d)].cap;
+        const unsigned long long* n_dev = d == 0 ? nullptr : s->d_counters + size_t(d - 1) * CNT_TOTAL + CNT_NEXT;
+        hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n)), dim3(BLOCK), 0, st, L, N, n, n_dev, d < D ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    // one strided copy: the CNT_COUNT plain counters of every level block
+    HIP_TRY(hipMemcpy2DAsync(s->h_counters, CNT_COUNT * sizeof(unsigned long long), s->d_counters, CNT_TOTAL * sizeof(unsigned long long),
+                             CNT_COUNT * sizeof(unsigned long long), size_t(D + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *overflow = false;
+    for (int d = 0; d < D; ++d)
+        if ((long long)s->h_counters[size_t(d) * CNT_COUNT + CNT_NEXT] > s->levels[size_t(d) + 1].cap) *overflow = true;
+    return RT_OK;
+}
+
 
 // color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
 int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool counters, rt_stats* stats) {
+    if (!stats && !counters && max_depth >= 0 && max_depth + 1 <= ASYNC_LEVELS && s->levels.size() > size_t(max_depth)) {
+        bool sized = true;
+        for (int d = 0; d <= max_depth; ++d) sized = sized && s->levels[size_t(d)].block != nullptr;
+        if (sized) {
+            bool overflow = false;
+            int rc = run_levels_async(s, st, n0, max_depth, &overflow);
+            if (rc != RT_OK || !overflow) return rc;
+        }
+    }
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_TOTAL * sizeof(unsigned long long), st));
     Timer tm{s, st, stats != nullptr};
     std::vector<long long> counts;
@@ -223,7 +282,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
         HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, (CNT_TOTAL - CNT_NEXT) * sizeof(unsigned long long), st));
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        { int rc = counters ? launch_trace<true>(s, st, L, n, remaining) : launch_trace<false>(s, st, L, n, remaining); if (rc != RT_OK) return rc; }
+        { int rc = counters ? launch_trace<true>(s, st, L, n, nullptr, remaining, s->d_counters) : launch_trace<false>(s, st, L, n, nullptr, remaining, s->d_counters); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
         if (counters && stats) {  // instrumented run: split the work counters per kernel class
@@ -235,14 +294,14 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
             }
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, next_cap, s->d_counters);
+        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, (const unsigned long long*)nullptr, next_cap, s->d_counters);
         tm.end();
         const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
         if (counters && stats) {  // instrumented run: one queue per launch, so that the work counters stay apart
             for (int phase = 1; phase <= 2; phase <<= 1) {
                 if (!(want & phase)) continue;
                 tm.begin(phase == 1 ? &stats->ms_shadow : &stats->ms_collect);
-                { int rc = launch_secondary<true>(s, st, L, n, phase); if (rc != RT_OK) return rc; }
+                { int rc = launch_secondary<true>(s, st, L, n, phase, s->d_counters); if (rc != RT_OK) return rc; }
                 tm.end();
                 if (phase == 1) stats->n_shadow_launches++;
                 HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -255,12 +314,12 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
             }
         } else if (want) {
             tm.begin(stats ? &stats->ms_shadow : nullptr);
-            { int rc = counters ? launch_secondary<true>(s, st, L, n, want) : launch_secondary<false>(s, st, L, n, want); if (rc != RT_OK) return rc; }
+            { int rc = counters ? launch_secondary<true>(s, st, L, n, want, s->d_counters) : launch_secondary<false>(s, st, L, n, want, s->d_counters); if (rc != RT_OK) return rc; }
             tm.end();
             if (stats && (want & 1)) stats->n_shadow_launches++;
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, remaining);
+        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, (const unsigned long long*)nullptr, remaining);
         tm.end();
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -281,10 +340,15 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
         const Level& L = s->levels[size_t(d)].L;
         const Level& N = has_next ? s->levels[size_t(d) + 1].L : L;
         hipLaunchKernelGGL(k_resolve, dim3(blocks_for(counts[size_t(d)])), dim3(BLOCK), 0, st, L, N, counts[size_t(d)],
-                           has_next ? 1 : 0);
+                           (const unsigned long long*)nullptr, has_next ? 1 : 0);
     }
     tm.end();
     HIP_TRY(hipGetLastError());
+    // give the levels this frame did not reach a (small) queue too, so that the next frame can be enqueued in one go
+    for (int d = int(counts.size()); d <= max_depth && d < ASYNC_LEVELS; ++d) {
+        int rc = ensure_level(s, size_t(d), 64);
+        if (rc != RT_OK) return rc;
+    }
     if (stats) {
         const unsigned long long* c = s->h_counters;
         stats->rays_reflect = (int64_t)c[CNT_REFLECT];
@@ -496,8 +560,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         double tr = mp[RT_MAT_TRANSPARENCY], rf = mp[RT_MAT_REFLECTIVE];
         if (!(std::fabs(tr - 0.) < EPS) || (rf > 0. && tr > 0.)) s->any_transparent = true;
     }
-    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), size_t(ASYNC_LEVELS) * CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), size_t(ASYNC_LEVELS) * CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&s->ev[0]) != hipSuccess || hipEventCreate(&s->ev[1]) != hipSuccess) {
         rt_set_error("could not create stream / counters: %s", hipGetErrorString(hipGetLastError()));
         return fail(RT_ERR_HIP);

@@ -983,9 +983,19 @@ __device__ __forceinline__ bool needs_walk(const DScene& S, const double* __rest
     return !near_eq(m[RT_MAT_TRANSPARENCY], 0.) || (m[RT_MAT_REFLECTIVE] > 0. && m[RT_MAT_TRANSPARENCY] > 0.);
 }
 
+// Ray count of a level: known to the host (`n_dev` == null), or — when a whole frame is enqueued without a host
+// round trip per level — read from the previous level's CNT_NEXT, clamped to the capacity `n` the host passes instead.
+__device__ __forceinline__ long long level_count(long long n, const unsigned long long* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const long long v = (long long)*n_dev;
+    return v < n ? v : n;
+}
+
 // `remaining` is the value color_at was called with at this level.
 template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n, int remaining, unsigned long long* counters) {
+__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
+                                                  unsigned long long* counters) {
+    const long long n = level_count(n_cap, n_dev);
     Feed feed;
     const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
     Work w = {};
@@ -1046,7 +1056,10 @@ struct TileSlots {
     long long base[3];                   // shadow queue, container queue, next level
 };
 
-__global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n, long long next_cap, unsigned long long* counters) {
+__global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const unsigned long long* n_dev, long long next_cap,
+                                                 unsigned long long* counters) {
+    const long long n = level_count(n_cap, n_dev);
+    if ((long long)blockIdx.x * TILE >= n) return;  // whole workgroup beyond the level
     __shared__ TileSlots ts;
     const long long tile0 = (long long)blockIdx.x * TILE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1177,7 +1190,9 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
     if (COUNT) flush_work(w, counters);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n, int remaining) {
+__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev,
+                                                  int remaining) {
+    const long long n = level_count(n_cap, n_dev);
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const int stage = L.mode[i];
@@ -1229,7 +1244,8 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
 }
 
 // Kernel: bottom-up resolve of one level == the tail of shade_hit (src/world.rs:68-78) + color_at's miss case.
-__global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n, int has_next) {
+__global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next) {
+    const long long n = level_count(n_cap, n_dev);
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     if (L.hkey[i] < 0) {  // miss -> BLACK

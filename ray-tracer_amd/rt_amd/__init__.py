@@ -633,8 +633,9 @@ class Camera:
         _chk(lib.rt_ray_for_pixel(C.byref(cd), len(px), px.ctypes.data_as(c_ip), py.ctypes.data_as(c_ip), _dp(o), _dp(d)))
         return o, d
 
-    def render(self, world, depth=DEFAULT_RECURSION, want_counters=False, rank=0, n_ranks=1):
-        """Camera::render (src/camera.rs:62-74) on the GPU."""
+    def render(self, world, depth=DEFAULT_RECURSION, want_counters=False, rank=0, n_ranks=1, want_stats=True):
+        """Camera::render (src/camera.rs:62-74) on the GPU.  want_stats=False passes no rt_stats, which lets the
+        library enqueue the whole frame without a host round trip per recursion level."""
         cd = self.desc()
         opts = RenderOpts(max_depth=depth, rank=rank, n_ranks=n_ranks, want_counters=int(want_counters), stream=None)
         rgb = np.zeros((self.vsize, self.hsize, 3))
@@ -642,7 +643,7 @@ class Camera:
         flags = np.zeros((self.vsize, self.hsize), dtype=np.uint8)
         st = Stats()
         _chk(lib.rt_render(world.scene(), C.byref(cd), C.byref(opts), _dp(rgb), ids.ctypes.data_as(c_ip),
-                           flags.ctypes.data_as(c_bp), C.byref(st)))
+                           flags.ctypes.data_as(c_bp), C.byref(st) if want_stats else None))
         return Image(rgb, ids, flags, st)
 
 

@@ -381,3 +381,33 @@ def test_glass_at_the_last_level(index):
         assert np.array_equal(np.isinf(g.rgb), np.isinf(o.rgb))
         ok = np.isfinite(o.rgb)
         assert float(np.abs(g.rgb[ok] - o.rgb[ok]).max(initial=0.)) < COLOR_TOL
+
+
+def test_whole_frame_enqueue_matches_the_level_by_level_walk():
+    # without rt_stats the library enqueues all levels at once (ray counts stay on the device); same pixels, and a
+    # view that spawns more rays than the queues were sized for must fall back, not truncate
+    w, cam = scenes.teapot_scene(200, 112)
+    ref = cam.render(w)                                  # level by level: sizes the queues
+    for _ in range(2):
+        a = cam.render(w, want_stats=False)
+        assert np.array_equal(a.rgb, ref.rgb) and np.array_equal(a.hit_id, ref.hit_id) and np.array_equal(a.flags, ref.flags)
+    for depth in (2, 0, 5):
+        a = cam.render(w, depth, want_stats=False)
+        b = cam.render(w, depth)
+        assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.hit_id, b.hit_id)
+    # far-away view first (few secondary rays, small queues), then the glass sphere filling the frame
+    far = Camera(200, 112, PI / 3)
+    far.transform = view_transform((0.5, 30., -60.), (0.2, 1.2, 0.), (0., 1., 0.))
+    w2, _ = scenes.teapot_scene(200, 112)
+    far.render(w2)
+    near = Camera(200, 112, PI / 3)
+    near.transform = view_transform((-3.6, 1.4, -5.2), (-3.6, 1.2, -2.6), (0., 1., 0.))
+    a = near.render(w2, want_stats=False)
+    b = near.render(w2)
+    assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.hit_id, b.hit_id)
+    assert b.stats.rays_refract > 4 * ref.stats.rays_refract // 10
+    # batched color_at takes the same route when no stats are asked for
+    o, d = _random_rays(5000, 21)
+    r1 = w.color_at_batch(o, d, 5)
+    r2 = w.color_at_batch(o, d, 5, want_stats=True)
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
