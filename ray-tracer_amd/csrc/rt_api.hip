@@ -162,7 +162,7 @@ struct Timer {  // accumulates device time of bracketed launches when enabled
     }
 };
 
-// Launches a persistent traversal kernel over `n_chunks` chunks of TBLOCK rays (an upper bound is fine: the kernel
+// Launches a persistent traversal kernel over `n_chunks` chunks of 64 rays (an upper bound is fine: the kernel
 // derives its own chunk count).  The grid is what the device can hold at once with this kernel's LDS footprint.
 template <class K, class... A>
 int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... args) {
@@ -180,7 +180,7 @@ int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... 
     hipLaunchKernelGGL(kernel, dim3(unsigned(grid)), dim3(TBLOCK), s->trav_lds_bytes, st, args...);
     return RT_OK;
 }
-inline long long chunks_for(long long n) { return (n + TBLOCK - 1) / TBLOCK; }
+inline long long chunks_for(long long n) { return (n + 63) / 64; }  // small launches spread over all CUs, a few chunks each
 
 template <bool COUNT>
 int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, int remaining,

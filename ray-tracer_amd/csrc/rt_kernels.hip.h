@@ -332,6 +332,41 @@ __device__ __forceinline__ double slab_rcp(double d) {
     return r2 == r2 ? r2 : r;
 }
 
+// f32 twin of the slab test for BVH nodes (never for the mesh box, never for a reference formula).  Measured: a
+// wavefront issues an f64 VALU instruction every 8-10 cycles against 4 for f32, and a node visit was ~75 % box
+// arithmetic.  Conservative by an explicit error budget, not by luck: with o_f = fl32(o), inv_f = fl32(1/d) and the
+// stored f32 planes p (already rounded outward), a_f = fl32(fl32(p - o_f) * inv_f) differs from the exact
+// (p - o) / d by at most 3 * 2^-24 |a| + 2^-24 |o / d|.  The test widens the [tmin, tmax] interval by
+// 2^-20 (|tmin| + |tmax|) + 2^-21 max_axis |o_f * inv_f| — four times that budget on each side.  A ray whose f32
+// origin, reciprocal or budget is not finite takes the f64 test instead.
+struct RayF {
+    float ox, oy, oz, ix, iy, iz, budget;
+    bool ok;
+};
+__device__ __forceinline__ RayF make_rayf(V3 o, V3 inv) {
+    RayF r;
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.ix = (float)inv.x; r.iy = (float)inv.y; r.iz = (float)inv.z;
+    const float e = fmaxf(fmaxf(fabsf(r.ox * r.ix), fabsf(r.oy * r.iy)), fabsf(r.oz * r.iz));
+    r.budget = e * 4.76837158203125e-07f;  // 2^-21
+    r.ok = fabsf(r.ox) < 3e38f && fabsf(r.oy) < 3e38f && fabsf(r.oz) < 3e38f && fabsf(r.ix) < 3e38f && fabsf(r.iy) < 3e38f &&
+           fabsf(r.iz) < 3e38f && r.budget < 3e38f;  // NaN fails every comparison
+    return r;
+}
+__device__ __forceinline__ bool bvh_box_f32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r, float tlo,
+                                            float thi, float& tnear) {
+    const float ax = (lox - r.ox) * r.ix, bx = (hix - r.ox) * r.ix;
+    const float ay = (loy - r.oy) * r.iy, by = (hiy - r.oy) * r.iy;
+    const float az = (loz - r.oz) * r.iz, bz = (hiz - r.oz) * r.iz;
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    float slack = 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax)) + r.budget;  // 2^-20
+    tnear = tmin - slack;
+    // a product that overflowed f32 is not an exact infinity: no culling on it
+    if (!(slack < 3e38f)) return true;
+    return !(tmin > tmax + slack) && !(tmax + slack < tlo) && !(tmin - slack > thi);
+}
+
 struct TriData {
     V3 p1, e1, e2;
     int node, smooth;
@@ -346,13 +381,14 @@ __device__ __forceinline__ TriData load_tri(const MeshTri* __restrict__ t) {
     return r;
 }
 
-__device__ __forceinline__ void cswap(double& ta, int& ca, double& tb, int& cb) {
-    if (tb < ta) { double t = ta; ta = tb; tb = t; int c = ca; ca = cb; cb = c; }
+__device__ __forceinline__ void cswap(float& ta, int& ca, float& tb, int& cb) {
+    if (tb < ta) { float t = ta; ta = tb; tb = t; int c = ca; ca = cb; cb = c; }
 }
 
 template <bool COUNT, class Sink, class E>
 __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, V3 inv, const Sink& sink,
                                              bool full_line, Work& w, E&& e) {
+    const RayF rf = make_rayf(o, inv);
     int sp = 0;
     int cur = root;
     while (true) {
@@ -361,13 +397,20 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             float lo[3][4], hi[3][4];
             int ch[4];
             if (cur < M.n_lds) {
-                const RT_LDS BvhNode* __restrict__ n = M.lds_nodes + cur;
+                // LDS copy is column-major (16-byte column k of node i at [k][i]): lanes reading the same column of
+                // different nodes spread over the banks instead of all landing on the banks a 128-byte stride shares
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const RT_LDS f32x4* __restrict__ col = (const RT_LDS f32x4*)M.lds_nodes;
+                const int N = M.n_lds;
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { lo[a][c] = n->lo[a][c]; hi[a][c] = n->hi[a][c]; }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ch[c] = n->child[c];
+                for (int a = 0; a < 3; ++a) {
+                    const f32x4 l = col[a * N + cur], h = col[(3 + a) * N + cur];
+                    lo[a][0] = l.x; lo[a][1] = l.y; lo[a][2] = l.z; lo[a][3] = l.w;
+                    hi[a][0] = h.x; hi[a][1] = h.y; hi[a][2] = h.z; hi[a][3] = h.w;
+                }
+                const i32x4 c4 = ((const RT_LDS i32x4*)M.lds_nodes)[6 * N + cur];
+                ch[0] = c4.x; ch[1] = c4.y; ch[2] = c4.z; ch[3] = c4.w;
             } else {
                 const BvhNode* __restrict__ n = S.bvh + cur;
 #pragma unroll
@@ -381,14 +424,26 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             bump<COUNT>(w.box, 4);
             const double tlo = full_line ? -INFINITY : sink.lo();
             const double thi = sink.hi();
-            double tn[4];
+            float tn[4];
+            if (rf.ok) {
+                const float tlo_f = __double2float_rd(tlo), thi_f = __double2float_ru(thi);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double t;  // all four tests run unconditionally: no branch per child
-                bool hit = bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
-                                   (double)hi[2][c], o, inv, tlo, thi, t) & (ch[c] != INT32_MIN);
-                tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
-                if (!hit) ch[c] = INT32_MIN;
+                for (int c = 0; c < 4; ++c) {  // all four tests run unconditionally: no branch per child
+                    float t;
+                    bool hit = bvh_box_f32(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t) &
+                               (ch[c] != INT32_MIN);
+                    tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
+                    if (!hit) ch[c] = INT32_MIN;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double t;
+                    bool hit = bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
+                                       (double)hi[2][c], o, inv, tlo, thi, t) & (ch[c] != INT32_MIN);
+                    tn[c] = hit ? (t == t ? (float)t : -INFINITY) : INFINITY;
+                    if (!hit) ch[c] = INT32_MIN;
+                }
             }
             // nearest first (order only matters for how soon the closest-hit bound tightens)
             cswap(tn[0], ch[0], tn[1], ch[1]);
@@ -634,6 +689,8 @@ struct Feed {
         const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
         next_static = wave;
         stride_static = (long long)gridDim.x * (TBLOCK / 64);
+        // a launch with at most two chunks per wavefront has nothing to balance: deal statically, no atomics at all
+        if (n_chunks <= 2 * stride_static) cnt = nullptr;
         if (cnt && threadIdx.x == 0) {
             sh->part = int(blockIdx.x % FEED_PARTS);
             sh->dry = 0;
@@ -694,7 +751,7 @@ __device__ __forceinline__ TravMem trav_setup(const DScene& S, Feed& feed, unsig
     const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(S.bvh);
     RT_LDS u32x4* dst = (RT_LDS u32x4*)trav_lds;
     const int n16 = S.n_lds * int(sizeof(BvhNode) / 16);
-    for (int k = threadIdx.x; k < n16; k += TBLOCK) dst[k] = src[k];
+    for (int k = threadIdx.x; k < n16; k += TBLOCK) dst[(k & 7) * S.n_lds + (k >> 3)] = src[k];  // column-major, see bvh_traverse
     __syncthreads();
     return M;
 }
