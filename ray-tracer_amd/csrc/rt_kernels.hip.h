@@ -459,13 +459,16 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             // ---- leaf: its (at most BVH_LEAF_MAX = 2) triangles arrive as one batch of loads
             const int code = ~cur;
             const int first = code >> 2, count = (code & 3) + 1;
-            const TriData ta = load_tri(S.mesh_tris + first);
-            const TriData tb = load_tri(S.mesh_tris + first + (count > 1 ? 1 : 0));
-            isect_triangle<COUNT>(o, d, ta.p1, ta.e1, ta.e2, ta.smooth, w,
-                                  [&](double tt, int k, double u, double v, int uv) { e(tt, ta.node * 4 + k, u, v, uv); });
-            if (count > 1)
-                isect_triangle<COUNT>(o, d, tb.p1, tb.e1, tb.e2, tb.smooth, w,
-                                      [&](double tt, int k, double u, double v, int uv) { e(tt, tb.node * 4 + k, u, v, uv); });
+            for (int k = 0; k < count; k += 2) {  // two triangles per batch of loads
+                const bool two = k + 1 < count;
+                const TriData ta = load_tri(S.mesh_tris + first + k);
+                const TriData tb = load_tri(S.mesh_tris + first + k + (two ? 1 : 0));
+                isect_triangle<COUNT>(o, d, ta.p1, ta.e1, ta.e2, ta.smooth, w,
+                                      [&](double tt, int kk, double u, double v, int uv) { e(tt, ta.node * 4 + kk, u, v, uv); });
+                if (two)
+                    isect_triangle<COUNT>(o, d, tb.p1, tb.e1, tb.e2, tb.smooth, w,
+                                          [&](double tt, int kk, double u, double v, int uv) { e(tt, tb.node * 4 + kk, u, v, uv); });
+            }
         }
         if (sp == 0) break;
         cur = stack_pop(M, --sp);

@@ -111,7 +111,8 @@ struct Compiler {
         size_t n = hi - lo;
         if (n <= size_t(BVH_LEAF_MAX)) return emit_leaf(refs, lo, hi);
 
-        // binned SAH on the longest centroid axis; falls back to an index median when it cannot separate
+        // binned SAH over all three centroid axes; falls back to an index median on the longest axis when no bin
+        // boundary separates the set
         int axis = 0;
         double ext = cb.hi[0] - cb.lo[0];
         for (int k = 1; k < 3; ++k)
@@ -122,48 +123,52 @@ struct Compiler {
         while ((size_t(1) << lg) < n) ++lg;
         // SAH may unbalance the tree; allow it only while a median-split subtree would still fit the depth bound
         if (ext > 0. && depth + lg + 2 < BVH2_MAX_DEPTH) {
-            constexpr int NB = 16;
-            Box bb[NB];
-            size_t cnt[NB] = {0};
-            for (auto& b : bb) b.reset();
-            double scale = double(NB) / ext;
-            auto bin_of = [&](const TriRef& r) {
-                int b = int((r.c[axis] - cb.lo[axis]) * scale);
-                return std::min(std::max(b, 0), NB - 1);
-            };
-            for (size_t i = lo; i < hi; ++i) {
-                int b = bin_of(refs[i]);
-                bb[b].add(refs[i].lo, refs[i].hi);
-                cnt[b]++;
-            }
+            constexpr int NB = 32;
             auto area = [](const Box& b) {
                 double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
                 if (!(dx >= 0.)) return 0.;
                 return dx * dy + dy * dz + dz * dx;
             };
-            double right_area[NB];
-            size_t right_cnt[NB];
-            Box acc;
-            acc.reset();
-            size_t c = 0;
-            for (int b = NB - 1; b > 0; --b) {
-                if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
-                c += cnt[b];
-                right_area[b] = area(acc);
-                right_cnt[b] = c;
-            }
-            acc.reset();
-            c = 0;
             double best = INF;
-            int best_b = -1;
-            for (int b = 0; b + 1 < NB; ++b) {
-                if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
-                c += cnt[b];
-                if (c == 0 || right_cnt[b + 1] == 0) continue;
-                double cost = area(acc) * double(c) + right_area[b + 1] * double(right_cnt[b + 1]);
-                if (cost < best) { best = cost; best_b = b; }
+            int best_b = -1, best_axis = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const double e = cb.hi[ax] - cb.lo[ax];
+                if (!(e > 0.)) continue;
+                Box bb[NB];
+                size_t cnt[NB] = {0};
+                for (auto& b : bb) b.reset();
+                const double scale = double(NB) / e;
+                for (size_t i = lo; i < hi; ++i) {
+                    int b = std::min(std::max(int((refs[i].c[ax] - cb.lo[ax]) * scale), 0), NB - 1);
+                    bb[b].add(refs[i].lo, refs[i].hi);
+                    cnt[b]++;
+                }
+                double right_area[NB];
+                size_t right_cnt[NB];
+                Box acc;
+                acc.reset();
+                size_t c = 0;
+                for (int b = NB - 1; b > 0; --b) {
+                    if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
+                    c += cnt[b];
+                    right_area[b] = area(acc);
+                    right_cnt[b] = c;
+                }
+                acc.reset();
+                c = 0;
+                for (int b = 0; b + 1 < NB; ++b) {
+                    if (cnt[b]) acc.add(bb[b].lo, bb[b].hi);
+                    c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    double cost = area(acc) * double(c) + right_area[b + 1] * double(right_cnt[b + 1]);
+                    if (cost < best) { best = cost; best_b = b; best_axis = ax; }
+                }
             }
             if (best_b >= 0) {
+                const double scale = double(NB) / (cb.hi[best_axis] - cb.lo[best_axis]);
+                auto bin_of = [&](const TriRef& r) {
+                    return std::min(std::max(int((r.c[best_axis] - cb.lo[best_axis]) * scale), 0), NB - 1);
+                };
                 auto it = std::partition(refs.begin() + long(lo), refs.begin() + long(hi),
                                          [&](const TriRef& r) { return bin_of(r) <= best_b; });
                 size_t m = size_t(it - refs.begin());

@@ -82,7 +82,7 @@ struct Program {
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err);
 
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
-constexpr int BVH_LEAF_MAX = 2;        // triangles per leaf (the device fetches a leaf's triangles as one batch)
+XX
 constexpr int BVH_STACK = 32;          // device traversal stack entries per ray: 3 pending siblings per BVH4 level
 constexpr int BVH2_MAX_DEPTH = 20;     // binary build depth bound; the collapse halves it: 3 * 10 <= BVH_STACK
 
