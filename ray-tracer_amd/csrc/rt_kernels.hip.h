@@ -456,7 +456,7 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             if (ch[1] != INT32_MIN) stack_push(M, sp++, ch[1]);
             if (ch[0] != INT32_MIN) { cur = ch[0]; continue; }
         } else {
-            // ---- leaf: its (at most BVH_LEAF_MAX = 2) triangles arrive as one batch of loads
+            // ---- leaf: at most BVH_LEAF_MAX = 4 triangles
             const int code = ~cur;
             const int first = code >> 2, count = (code & 3) + 1;
             for (int k = 0; k < count; k += 2) {  // two triangles per batch of loads
