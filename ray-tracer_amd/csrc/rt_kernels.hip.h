@@ -1337,15 +1337,19 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n
 
 // Kernel: level-0 colours -> caller's buffers, interleaved RGB.  frame == 0: shard-local order; frame == 1:
 // scatter into the full row-major frame (Canvas layout, src/canvas.rs:25-27).
-__global__ __launch_bounds__(BLOCK) void k_output(DScene S, Level L, long long n, double* rgb, int32_t* hit_id, uint8_t* flags) {
+// `chains` > 1: this level holds sub-shard `chain` of the shard (every chains-th 8x8 tile); its 64-slot tiles are
+// written to their interleaved places in the shard buffer.
+__global__ __launch_bounds__(BLOCK) void k_output(DScene S, Level L, long long n, double* rgb, int32_t* hit_id, uint8_t* flags,
+                                                  int chains, int chain) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    rgb[3 * i] = L.cr[i]; rgb[3 * i + 1] = L.cg[i]; rgb[3 * i + 2] = L.cb[i];
+    const long long o = ((i >> 6) * chains + chain) * 64 + (i & 63);
+    rgb[3 * o] = L.cr[i]; rgb[3 * o + 1] = L.cg[i]; rgb[3 * o + 2] = L.cb[i];
     if (hit_id) {
         int key = L.hkey[i];
-        hit_id[i] = key >= 0 ? S.node_object_id[key >> 2] : 0;
+        hit_id[o] = key >= 0 ? S.node_object_id[key >> 2] : 0;
     }
-    if (flags) flags[i] = L.flags[i];
+    if (flags) flags[o] = L.flags[i];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_slots, const double* __restrict__ rgb_in,

@@ -263,6 +263,11 @@ def test_full_size_properties_c3():
     assert a.stats.rays_primary == 1919 * 1079
     assert a.stats.rays_shadow == a.stats.shaded_nodes * len(w.lights)
     assert np.isfinite(a.rgb).all() and not a.flags.any()
+    # without rt_stats a frame this size runs as concurrent sub-frame chains on their own streams (first such frame
+    # sizes the chains' queues level by level, the next ones are enqueued whole): same pixels every time
+    for _ in range(3):
+        c = cam.render(w, want_stats=False)
+        assert np.array_equal(c.rgb, a.rgb) and np.array_equal(c.hit_id, a.hit_id) and np.array_equal(c.flags, a.flags)
     # the frame is the same however it is tile-sharded (pixel values must not depend on the partition)
     acc = np.zeros_like(a.rgb)
     ids = np.zeros_like(a.hit_id)
