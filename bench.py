@@ -39,6 +39,7 @@ B_RAY_IO = {"k_trace": 48 + 17, "k_trace_hit": 56, "shadow": 4 + 48 + 1, "contai
 
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
+FP64_VALU_MEASURED_TFLOPS = 35.6  # scripts/fp64_roof.hip on the box (profiles/fp64_roof.json): v_mul_f64 + v_add_f64 chains, 8 waves/SIMD
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -193,6 +194,7 @@ def main():
         achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         roofline = {"kernel": dom, "bound": "fp64_valu", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
+                    "peak_measured": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured": round(achieved / FP64_VALU_MEASURED_TFLOPS, 5),
                     "launches_per_frame": n_launch, "avg_launch_ms": round(ms[dom] / n_launch, 5),
                     "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
