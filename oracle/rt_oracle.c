@@ -650,15 +650,28 @@ static ray_t mk_ray(const double* o, const double* dd) {
 
 /* Camera::render (src/camera.rs:62-74).  stride > 1 renders only pixels with x % stride == 0 && y % stride == 0
  * (the CPU-baseline sample); everything else stays 0. */
+/* Rows [y0, y1) of Camera::render (every stride-th row and column): lets a harness spread one frame over processes
+ * (this file keeps its counters in globals, so one render per process). */
+int orc_render_rows(const rt_scene_desc* d, const rt_camera_desc* cam, int depth, int stride, int y0, int y1, double* rgb,
+                    int32_t* hit_id, uint8_t* flags, orc_stats* stats);
+
 int orc_render(const rt_scene_desc* d, const rt_camera_desc* cam, int depth, int stride, double* rgb, int32_t* hit_id,
                uint8_t* flags, orc_stats* stats) {
-    if (!d || !cam || !rgb || cam->hsize < 1 || cam->vsize < 1 || stride < 1) return RT_ERR_BAD_ARG;
+    if (!cam) return RT_ERR_BAD_ARG;
+    return orc_render_rows(d, cam, depth, stride, 0, cam->vsize - 1, rgb, hit_id, flags, stats);
+}
+
+int orc_render_rows(const rt_scene_desc* d, const rt_camera_desc* cam, int depth, int stride, int y0, int y1, double* rgb,
+                    int32_t* hit_id, uint8_t* flags, orc_stats* stats) {
+    if (!d || !cam || !rgb || cam->hsize < 1 || cam->vsize < 1 || stride < 1 || y0 < 0) return RT_ERR_BAD_ARG;
+    if (y1 > cam->vsize - 1) y1 = cam->vsize - 1;   /* 0..vsize-1: last row skipped */
+    y0 = (y0 + stride - 1) / stride * stride;       /* the sample grid is anchored at row 0 */
     memset(&g_stats, 0, sizeof g_stats);
     size_t npx = (size_t)cam->hsize * (size_t)cam->vsize;
     memset(rgb, 0, npx * 3 * sizeof(double)); /* Canvas::new: all BLACK */
     if (hit_id) memset(hit_id, 0, npx * sizeof(int32_t));
     if (flags) memset(flags, 0, npx);
-    for (int y = 0; y < cam->vsize - 1; y += stride) {      /* 0..vsize-1: last row skipped  */
+    for (int y = y0; y < y1; y += stride) {
         for (int x = 0; x < cam->hsize - 1; x += stride) {  /* 0..hsize-1: last column skipped */
             ray_t r = ray_for_pixel(cam, (unsigned)x, (unsigned)y);
             g_flags = 0;

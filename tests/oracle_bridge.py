@@ -27,6 +27,7 @@ class OrcStats(C.Structure):
 
 
 olib.orc_render.argtypes = [DESC, C.POINTER(rt.CameraDesc), C.c_int, C.c_int, c_dp, c_ip, c_bp, C.POINTER(OrcStats)]
+olib.orc_render_rows.argtypes = [DESC, C.POINTER(rt.CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_ip, c_bp, C.POINTER(OrcStats)]
 olib.orc_color_at.argtypes = [DESC, C.c_int64, c_dp, c_dp, C.c_int, c_dp, c_ip, c_bp]
 olib.orc_intersect_world.argtypes = [DESC, C.c_int64, c_dp, c_dp, C.c_int, c_ip, c_dp, c_ip]
 olib.orc_is_shadowed.argtypes = [DESC, C.c_int64, c_dp, c_bp]
@@ -57,15 +58,17 @@ def _ok(rc):
     return rc
 
 
-def render(world, camera, depth=rt.DEFAULT_RECURSION, stride=1):
-    """Camera::render by the oracle.  Returns an rt.Image whose stats is an OrcStats."""
+def render(world, camera, depth=rt.DEFAULT_RECURSION, stride=1, rows=None):
+    """Camera::render by the oracle (rows = (y0, y1) restricts it to a band).  Returns an rt.Image whose stats is
+    an OrcStats."""
     cd = camera.desc()
     rgb = np.zeros((camera.vsize, camera.hsize, 3))
     ids = np.zeros((camera.vsize, camera.hsize), dtype=np.int32)
     flags = np.zeros((camera.vsize, camera.hsize), dtype=np.uint8)
     st = OrcStats()
-    _ok(olib.orc_render(world.flatten(), C.byref(cd), depth, stride, _dp(rgb), ids.ctypes.data_as(c_ip),
-                        flags.ctypes.data_as(c_bp), C.byref(st)))
+    y0, y1 = rows if rows is not None else (0, camera.vsize - 1)
+    _ok(olib.orc_render_rows(world.flatten(), C.byref(cd), depth, stride, int(y0), int(y1), _dp(rgb), ids.ctypes.data_as(c_ip),
+                             flags.ctypes.data_as(c_bp), C.byref(st)))
     return rt.Image(rgb, ids, flags, st)
 
 
