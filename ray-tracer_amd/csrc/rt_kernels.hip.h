@@ -6,10 +6,12 @@
 // become fmax/fmin (both ignore a NaN operand).  Tuples drop w on the device: rt_scene_create only accepts affine
 // inverses, for which w stays exactly 1 (points) or 0 (vectors) and its terms add exactly 0.0.
 //
-// Execution model: one ray per lane, 256-thread workgroups (4 wavefronts).  A frame is a wavefront pipeline over
-// recursion levels: trace(level) -> shade(level) [shadow + container traversals inline, spawns level+1 with
-// ballot/mbcnt compaction] ... then resolve(level) from the deepest level up, which evaluates shade_hit's blend in
-// the reference's own order (src/world.rs:68-78) so colours match the recursive form bit for bit.
+// Execution model: one ray per lane.  A frame is a wavefront pipeline over recursion levels:
+// k_trace(level) -> k_queue(level) -> k_secondary(level) -> k_finish(level) ... then k_resolve(level) from the deepest
+// level up, which evaluates shade_hit's blend in the reference's own order (src/world.rs:68-78) so colours match the
+// recursive form bit for bit.  Traversal kernels (k_trace, k_secondary, k_list, k_shadow_points) are persistent
+// 1024-lane workgroups, one per CU, fed 64-ray chunks per wavefront; the rest are plain streaming kernels.
+// DESIGN.md section 4 has the why and the measurements.
 #pragma once
 #include <hip/hip_runtime.h>
 
