@@ -391,6 +391,8 @@ template <bool COUNT, class Sink, class E>
 __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, V3 inv, const Sink& sink,
                                              bool full_line, Work& w, E&& e) {
     const RayF rf = make_rayf(o, inv);
+    // A launch lasts as long as its slowest wavefront, and the slow ones are in here: let them issue first.
+    __builtin_amdgcn_s_setprio(3);
     int sp = 0;
     int cur = root;
     while (true) {
@@ -475,6 +477,7 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
         if (sp == 0) break;
         cur = stack_pop(M, --sp);
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
