@@ -373,6 +373,12 @@ struct TriData {
     V3 p1, e1, e2;
     int node, smooth;
 };
+// The compiler sinks loads into the branch that first uses them; for a triangle test that meant three dependent
+// memory round trips per triangle (edges -> det test -> p1 -> u test ... -> node id), ~8000 cycles per 4-triangle
+// leaf.  pin() makes a loaded value count as used where it stands, so a leaf's loads are all issued together.
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(V3& a) { pin(a.x); pin(a.y); pin(a.z); }
 __device__ __forceinline__ TriData load_tri(const MeshTri* __restrict__ t) {
     TriData r;
     r.p1 = mk(t->p1[0], t->p1[1], t->p1[2]);
@@ -465,8 +471,10 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             const int first = code >> 2, count = (code & 3) + 1;
             for (int k = 0; k < count; k += 2) {  // two triangles per batch of loads
                 const bool two = k + 1 < count;
-                const TriData ta = load_tri(S.mesh_tris + first + k);
-                const TriData tb = load_tri(S.mesh_tris + first + k + (two ? 1 : 0));
+                TriData ta = load_tri(S.mesh_tris + first + k);
+                TriData tb = load_tri(S.mesh_tris + first + k + (two ? 1 : 0));
+                pin(ta.p1); pin(ta.e1); pin(ta.e2); pin(ta.node); pin(ta.smooth);
+                pin(tb.p1); pin(tb.e1); pin(tb.e2); pin(tb.node); pin(tb.smooth);
                 isect_triangle<COUNT>(o, d, ta.p1, ta.e1, ta.e2, ta.smooth, w,
                                       [&](double tt, int kk, double u, double v, int uv) { e(tt, ta.node * 4 + kk, u, v, uv); });
                 if (two)
