@@ -76,6 +76,13 @@ struct rt_scene {
     static constexpr int MAX_CHAINS = 4;
     Parked parked[MAX_CHAINS];  // [0] unused except for `done`
     hipEvent_t ev_in = nullptr;
+    // The enqueue of a whole frame (all chains, ~45 launches each) costs the host about as long as the GPU needs to
+    // run it, which kept the chains from overlapping.  So the enqueue is captured once into a HIP graph and replayed
+    // with one call while everything it bakes in stays the same (camera, shard, depth, output pointers, queue
+    // blocks): `graph_key` is the byte image of those.
+    hipGraphExec_t graph_exec = nullptr;
+    std::string graph_key;
+    bool use_graph = true;
     int max_chains = 2;  // measured on the 1080p teapot frame: 1 chain 2.14 ms, 2 chains 2.07 ms, 4 chains 3.09 ms (RT_AMD_CHAINS overrides)
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
@@ -453,35 +460,94 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     if (n_slots == 0) return RT_OK;
     // ---- several sub-frame chains in flight (only the plain path: no stats, no instrumentation)
     const int K = int(std::min<long long>(s->max_chains, std::max<long long>(1, n_slots / 65536)));
-    if (!stats && !opts->want_counters && K > 1) {
+    if (!stats && !opts->want_counters) {
         const int D = opts->max_depth;
-        HIP_TRY(hipEventRecord(s->ev_in, st));
-        bool enqueued[rt_scene::MAX_CHAINS] = {false, false, false, false};
         CameraParams ck[rt_scene::MAX_CHAINS];
         long long nk[rt_scene::MAX_CHAINS] = {0, 0, 0, 0};
+        bool all_sized = true;
         for (int k = 0; k < K; ++k) {
             long long nv = 0;
             rc = camera_params(cam, opts->rank + k * opts->n_ranks, opts->n_ranks * K, ck[k], nk[k], nv);
             if (rc != RT_OK) return rc;
             if (nk[k] == 0) continue;
             ChainScope scope(s, k);
-            hipStream_t sk = s->parked[k].stream;
-            HIP_TRY(hipStreamWaitEvent(sk, s->ev_in, 0));
             rc = ensure_level(s, 0, nk[k]);
             if (rc != RT_OK) return rc;
-            if (levels_sized_for_async(s, D, false, nullptr)) {
-                hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, ck[k], s->levels[0].L, nk[k]);
-                rc = enqueue_levels_async(s, sk, nk[k], D);
+            all_sized = all_sized && levels_sized_for_async(s, D, false, nullptr);
+        }
+        // everything a captured frame bakes in
+        std::string key;
+        auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
+        put(cam, sizeof *cam); put(&opts->rank, sizeof opts->rank); put(&opts->n_ranks, sizeof opts->n_ranks);
+        put(&D, sizeof D); put(&K, sizeof K); put(&d_rgb, sizeof d_rgb); put(&d_id, sizeof d_id); put(&d_flags, sizeof d_flags);
+        put(&st, sizeof st);
+        for (int k = 0; k < K; ++k) {
+            ChainScope scope(s, k);
+            for (int d = 0; d <= D && size_t(d) < s->levels.size(); ++d) { put(&s->levels[size_t(d)].block, sizeof(void*)); put(&s->levels[size_t(d)].cap, sizeof(long long)); }
+        }
+        // chain k's whole frame on stream sk (plain enqueue, or recorded while `st` is capturing)
+        auto enqueue_chain = [&](int k) -> int {
+            ChainScope scope(s, k);
+            hipStream_t sk = s->parked[k].stream;
+            HIP_TRY(hipStreamWaitEvent(sk, s->ev_in, 0));
+            hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, ck[k], s->levels[0].L, nk[k]);
+            int rc2 = enqueue_levels_async(s, sk, nk[k], D);
+            if (rc2 != RT_OK) return rc2;
+            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k);
+            HIP_TRY(hipEventRecord(s->parked[k].done, sk));
+            return RT_OK;
+        };
+        bool ran_async = false;
+        if (all_sized && s->use_graph) {
+            if (!s->graph_exec || key != s->graph_key) {
+                if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+                hipGraph_t graph = nullptr;
+                HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                int rcc = RT_OK;
+                if (hipEventRecord(s->ev_in, st) != hipSuccess) rcc = RT_ERR_HIP;
+                for (int k = 0; k < K && rcc == RT_OK; ++k)
+                    if (nk[k]) {
+                        rcc = enqueue_chain(k);
+                        if (rcc == RT_OK && hipStreamWaitEvent(st, s->parked[k].done, 0) != hipSuccess) rcc = RT_ERR_HIP;
+                    }
+                hipError_t ee = hipStreamEndCapture(st, &graph);
+                if (rcc != RT_OK || ee != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    s->use_graph = false;  // capture is not available here: plain enqueue from now on
+                } else {
+                    hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    if (ei != hipSuccess) { s->graph_exec = nullptr; (void)hipGetLastError(); s->use_graph = false; }
+                    else s->graph_key = key;
+                }
+            }
+            if (s->graph_exec) {
+                HIP_TRY(hipGraphLaunch(s->graph_exec, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                ran_async = true;
+            }
+        }
+        bool enqueued[rt_scene::MAX_CHAINS] = {false, false, false, false};
+        if (ran_async) {
+            for (int k = 0; k < K; ++k) enqueued[k] = nk[k] != 0;
+        } else {
+            HIP_TRY(hipEventRecord(s->ev_in, st));
+            for (int k = 0; k < K; ++k) {
+                if (nk[k] == 0) continue;
+                bool sized;
+                { ChainScope scope(s, k); sized = levels_sized_for_async(s, D, false, nullptr); }
+                if (!sized) continue;
+                rc = enqueue_chain(k);
                 if (rc != RT_OK) return rc;
-                hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k);
                 enqueued[k] = true;
             }
-            HIP_TRY(hipEventRecord(s->parked[k].done, sk));
+            HIP_TRY(hipGetLastError());
+            for (int k = 0; k < K; ++k)
+                if (enqueued[k]) HIP_TRY(hipEventSynchronize(s->parked[k].done));
         }
-        HIP_TRY(hipGetLastError());
         for (int k = 0; k < K; ++k) {
             if (nk[k] == 0) continue;
-            HIP_TRY(hipEventSynchronize(s->parked[k].done));
             ChainScope scope(s, k);
             if (enqueued[k] && !levels_async_overflowed(s, D)) continue;
             // first frame of this chain, or a queue overflowed: level-by-level walk (sizes the queues), on the caller's stream
@@ -490,6 +556,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
             if (rc != RT_OK) return rc;
             hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
         }
         return RT_OK;
     }
@@ -659,6 +726,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
                  hipHostMalloc(reinterpret_cast<void**>(&p.h_counters), size_t(ASYNC_LEVELS) * CNT_COUNT * sizeof(unsigned long long)) == hipSuccess;
         if (!ok) { rt_set_error("could not create chain %d: %s", k, hipGetErrorString(hipGetLastError())); return fail(RT_ERR_HIP); }
     }
+    if (const char* e = std::getenv("RT_AMD_GRAPH")) s->use_graph = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_AMD_CHAINS")) s->max_chains = std::min(std::max(std::atoi(e), 1), int(rt_scene::MAX_CHAINS));
     *out = s;
     return RT_OK;
@@ -681,6 +749,7 @@ void rt_scene_destroy(rt_scene* s) {
         if (p.done) (void)hipEventDestroy(p.done);
         if (p.stream) (void)hipStreamDestroy(p.stream);
     }
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     for (GrowBuf* b : {&s->out_rgb, &s->out_id, &s->out_flags, &s->frame_rgb, &s->frame_id, &s->frame_flags, &s->in_a, &s->in_b,
                        &s->misc_a, &s->misc_b, &s->misc_c})
