@@ -291,6 +291,38 @@ __device__ __forceinline__ void isect_triangle(V3 o, V3 d, V3 point1, V3 edge_ve
     e(t, 0, u, v, smooth);
 }
 
+// Two triangles at once, no early exits: the same operations in the same order as isect_triangle, evaluated for both
+// triangles side by side and accepted by mask.  Measured on the device: a dependent VALU instruction issues ~20 cycles
+// after its producer when the wavefront is alone on its SIMD (the tail of every launch), ~8 with four independent
+// chains — so two interleaved, branch-free tests finish sooner than two short-circuited ones, and in a wavefront
+// whose lanes disagree every exit path was executed anyway.  Values computed past a failed test are never used.
+struct TriHit {
+    bool ok;
+    double t, u, v;
+};
+template <bool COUNT>
+__device__ __forceinline__ TriHit tri_eval(V3 o, V3 d, V3 point1, V3 edge_vector1, V3 edge_vector2, bool enabled, Work& w) {
+    V3 dir_cross_e2 = cross(d, edge_vector2);
+    double determinant = dot(edge_vector1, dir_cross_e2);
+    double f = 1.0 / determinant;
+    V3 p1_to_origin = vsub(o, point1);
+    double u = f * dot(p1_to_origin, dir_cross_e2);
+    V3 origin_cross_e1 = cross(p1_to_origin, edge_vector1);
+    double v = f * dot(d, origin_cross_e1);
+    double t = f * dot(edge_vector2, origin_cross_e1);
+    const bool det_ok = !(fabs(determinant) < EPS);
+    const bool u_ok = !(u < 0. || u > 1.);
+    const bool v_ok = !(v < 0. || (u + v) > 1.);
+    if (COUNT && enabled) {
+        ++w.tri;
+        if (!det_ok) ++w.tri_det;
+        else if (!u_ok) ++w.tri_u;
+        else if (!v_ok) ++w.tri_v;
+    }
+    TriHit h = {enabled && det_ok && u_ok && v_ok, t, u, v};
+    return h;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Acceleration BVH4 over the triangle meshes (non-semantic: only decides which triangles get tested).
 // Boxes are padded on the host and stored as outward-rounded f32; the slab test below runs in f64 and is
@@ -475,11 +507,10 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 TriData tb = load_tri(S.mesh_tris + first + k + (two ? 1 : 0));
                 pin(ta.p1); pin(ta.e1); pin(ta.e2); pin(ta.node); pin(ta.smooth);
                 pin(tb.p1); pin(tb.e1); pin(tb.e2); pin(tb.node); pin(tb.smooth);
-                isect_triangle<COUNT>(o, d, ta.p1, ta.e1, ta.e2, ta.smooth, w,
-                                      [&](double tt, int kk, double u, double v, int uv) { e(tt, ta.node * 4 + kk, u, v, uv); });
-                if (two)
-                    isect_triangle<COUNT>(o, d, tb.p1, tb.e1, tb.e2, tb.smooth, w,
-                                          [&](double tt, int kk, double u, double v, int uv) { e(tt, tb.node * 4 + kk, u, v, uv); });
+                const TriHit ha = tri_eval<COUNT>(o, d, ta.p1, ta.e1, ta.e2, true, w);
+                const TriHit hb = tri_eval<COUNT>(o, d, tb.p1, tb.e1, tb.e2, two, w);
+                if (ha.ok) e(ha.t, ta.node * 4, ha.u, ha.v, ta.smooth);
+                if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth);
             }
         }
         if (sp == 0) break;
