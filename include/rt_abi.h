@@ -283,6 +283,16 @@ int rt_intersect_world(rt_scene* scene, int64_t n_rays, const double* origins, c
 /* World::is_shadowed (src/world.rs:92-107) for a batch of points: out [n_points][n_lights], 1 = shadowed. */
 int rt_is_shadowed(rt_scene* scene, int64_t n_points, const double* points, uint8_t* out);
 
+/* Canvas::canvas_to_ppm (src/canvas.rs:33-84) + scale_color (src/canvas.rs:86-98) on the device, byte for byte:
+ * "P3\n{w} {h}\n255\n", then per canvas row the 3*w quantised values, a value that would make a line reach 70
+ * characters starts a new line, every row ends its line.  d_rgb_frame: DEVICE pointer, row-major vsize x hsize x 3 f64
+ * (what rt_assemble / rt_render_shard leave in HBM).  d_quantised_out: DEVICE pointer or NULL, vsize x hsize x 3 u8
+ * (the scale_color values: 8x smaller than the f64 frame for a gather or a D2H copy).  ppm_out: HOST buffer of
+ * `cap` bytes or NULL.  Returns the length of the PPM text in bytes (whether or not it fitted; nothing is written
+ * past cap), or a negative RT_ERR_* code. */
+int64_t rt_canvas_to_ppm(rt_scene* scene, const double* d_rgb_frame, int32_t hsize, int32_t vsize, uint8_t* d_quantised_out,
+                         char* ppm_out, int64_t cap);
+
 /* Camera::ray_for_pixel (src/camera.rs:37-60) for a batch of pixels, evaluated by the device ray-generation
  * code on device 0: origins_out / directions_out [n][3] (host). */
 int rt_ray_for_pixel(const rt_camera_desc* camera, int64_t n, const int32_t* px, const int32_t* py, double* origins_out,

@@ -841,6 +841,41 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     return RT_OK;
 }
 
+int64_t rt_canvas_to_ppm(rt_scene* s, const double* d_rgb_frame, int32_t hsize, int32_t vsize, uint8_t* d_quantised_out, char* ppm_out,
+                         int64_t cap) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!d_rgb_frame || hsize < 1 || vsize < 1 || cap < 0 || (cap > 0 && !ppm_out)) { rt_set_error("bad argument"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = s->stream;
+    const long long n = (long long)hsize * vsize * 3;
+    const int vpr = hsize * 3;
+    int rc;
+    uint8_t* q = d_quantised_out;
+    if (!q) {
+        if ((rc = grow(s->misc_a, size_t(n))) != RT_OK) return rc;
+        q = static_cast<uint8_t*>(s->misc_a.p);
+    }
+    if ((rc = grow(s->misc_b, size_t(vsize + 1) * sizeof(long long))) != RT_OK) return rc;
+    long long* rows = static_cast<long long*>(s->misc_b.p);
+    hipLaunchKernelGGL(k_quantise, dim3(blocks_for(n)), dim3(BLOCK), 0, st, d_rgb_frame, n, q);
+    hipLaunchKernelGGL(k_ppm_row_bytes, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, q, vpr, (int)vsize, rows);
+    hipLaunchKernelGGL(k_ppm_scan, dim3(1), dim3(BLOCK), 0, st, rows, (int)vsize);
+    HIP_TRY(hipGetLastError());
+    long long body = 0;
+    HIP_TRY(hipMemcpyAsync(&body, rows + vsize, sizeof body, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    char header[64];
+    const int hl = std::snprintf(header, sizeof header, "P3\n%d %d\n255\n", hsize, vsize);
+    const int64_t total = hl + body;
+    if (!ppm_out || cap < total) return total;  // the length alone (call again with a buffer that holds it)
+    if ((rc = grow(s->misc_c, size_t(body))) != RT_OK) return rc;
+    hipLaunchKernelGGL(k_ppm_write, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, q, vpr, (int)vsize, rows, static_cast<char*>(s->misc_c.p));
+    HIP_TRY(hipGetLastError());
+    std::memcpy(ppm_out, header, size_t(hl));
+    HIP_TRY(hipMemcpyAsync(ppm_out + hl, s->misc_c.p, size_t(body), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return total;
+}
+
 int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t remaining, double* rgb_out,
                 int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;

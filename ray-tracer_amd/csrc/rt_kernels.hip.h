@@ -1459,6 +1459,78 @@ __global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Canvas::canvas_to_ppm on the device (src/canvas.rs:33-98).  Every value is followed by exactly one separator
+// (' ', or '\n' where the reference wraps or ends the row), so a row's byte length is the sum of (digits + 1) over
+// its 3*w values whatever the wrapping: row offsets come from a scan, only the choice of separator is sequential
+// (greedy line fill restarted at every row).
+
+__device__ __forceinline__ int scale_color(double color_value) {  // src/canvas.rs:86-98
+    if (color_value > 1.0) return 255;
+    if (color_value < 0.0) return 0;
+    double scaled = color_value * 255.;
+    if (scaled != scaled) return 0;  // `as i32` maps NaN to 0
+    return (int)round(scaled);       // f64::round: half away from zero
+}
+
+__global__ __launch_bounds__(BLOCK) void k_quantise(const double* __restrict__ rgb, long long n, uint8_t* __restrict__ q) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) q[i] = (uint8_t)scale_color(rgb[i]);
+}
+
+__device__ __forceinline__ int digits_of(int v) { return v >= 100 ? 3 : v >= 10 ? 2 : 1; }
+
+// one thread per canvas row: bytes of the row's text
+__global__ __launch_bounds__(BLOCK) void k_ppm_row_bytes(const uint8_t* __restrict__ q, int values_per_row, int rows, long long* __restrict__ bytes) {
+    int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= rows) return;
+    const uint8_t* __restrict__ p = q + (size_t)r * values_per_row;
+    long long total = 0;
+    for (int k = 0; k < values_per_row; ++k) total += digits_of(p[k]) + 1;
+    bytes[r] = total;
+}
+
+// single workgroup: exclusive scan of the row sizes in place; bytes[rows] receives the total
+__global__ __launch_bounds__(BLOCK) void k_ppm_scan(long long* __restrict__ bytes, int rows) {
+    __shared__ long long part[BLOCK];
+    const int per = (rows + BLOCK - 1) / BLOCK;
+    const int lo = threadIdx.x * per, hi = min(lo + per, rows);
+    long long sum = 0;
+    for (int r = lo; r < hi; ++r) sum += bytes[r];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int k = 0; k < BLOCK; ++k) { long long c = part[k]; part[k] = run; run += c; }
+        bytes[rows] = run;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int r = lo; r < hi; ++r) { long long c = bytes[r]; bytes[r] = run; run += c; }
+}
+
+// one thread per canvas row: the row's text at its offset
+__global__ __launch_bounds__(BLOCK) void k_ppm_write(const uint8_t* __restrict__ q, int values_per_row, int rows,
+                                                     const long long* __restrict__ offsets, char* __restrict__ text) {
+    int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= rows) return;
+    const uint8_t* __restrict__ p = q + (size_t)r * values_per_row;
+    char* out = text + offsets[r];
+    int line = 0;  // characters in the current line, trailing space included (String::len in the reference)
+    for (int k = 0; k < values_per_row; ++k) {
+        const int v = p[k], nd = digits_of(v);
+        if (k > 0) {
+            if (line + nd >= 70) { *out++ = '\n'; line = 0; }  // the trailing space becomes the line break
+            else *out++ = ' ';
+        }
+        if (nd == 3) *out++ = char('0' + v / 100);
+        if (nd >= 2) *out++ = char('0' + (v / 10) % 10);
+        *out++ = char('0' + v % 10);
+        line += nd + 1;
+    }
+    *out++ = '\n';
+}
+
 // Kernel: load caller rays into level 0 (rt_color_at).
 __global__ __launch_bounds__(BLOCK) void k_load_rays(Level L, long long n, const double* __restrict__ origins,
                                                      const double* __restrict__ dirs) {

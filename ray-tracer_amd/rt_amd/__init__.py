@@ -104,7 +104,7 @@ class CMaterial(C.Structure):  # rth_material
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
                "rt_render_shard", "rt_assemble", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
-               "rt_ray_for_pixel", "rt_last_error"]
+               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
                 "rth_triangle_new", "rth_smooth_triangle_new", "rth_csg_new", "rth_hexagon", "rth_shape_clone",
@@ -131,6 +131,8 @@ lib.rt_color_at.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, 
 lib.rt_intersect_world.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_ip, c_dp, c_ip]
 lib.rt_is_shadowed.argtypes = [C.c_void_p, C.c_int64, c_dp, c_bp]
 lib.rt_ray_for_pixel.argtypes = [C.POINTER(CameraDesc), C.c_int64, c_ip, c_ip, c_dp, c_dp]
+lib.rt_canvas_to_ppm.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64]
+lib.rt_canvas_to_ppm.restype = C.c_int64
 
 for _n in ("rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform", "rth_matmul",
            "rth_material_default", "rth_shape_free", "rth_world_free"):
@@ -645,6 +647,19 @@ class Camera:
         _chk(lib.rt_render(world.scene(), C.byref(cd), C.byref(opts), _dp(rgb), ids.ctypes.data_as(c_ip),
                            flags.ctypes.data_as(c_bp), C.byref(st) if want_stats else None))
         return Image(rgb, ids, flags, st)
+
+
+def canvas_to_ppm_device(scene, d_rgb_frame, hsize, vsize, d_quantised=None):
+    """Canvas::canvas_to_ppm (src/canvas.rs:33-98) encoded on the GPU from a frame that lives in HBM.
+    d_rgb_frame / d_quantised: device pointers (ints).  Returns the PPM text as bytes."""
+    n = lib.rt_canvas_to_ppm(scene, d_rgb_frame, hsize, vsize, d_quantised, None, 0)
+    if n < 0:
+        raise RtError(int(n), last_error())
+    buf = C.create_string_buffer(int(n))
+    m = lib.rt_canvas_to_ppm(scene, d_rgb_frame, hsize, vsize, d_quantised, buf, n)
+    if m < 0:
+        raise RtError(int(m), last_error())
+    return buf.raw[:int(m)]
 
 
 def check_exports():

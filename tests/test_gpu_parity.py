@@ -416,3 +416,52 @@ def test_whole_frame_enqueue_matches_the_level_by_level_walk():
     r1 = w.color_at_batch(o, d, 5)
     r2 = w.color_at_batch(o, d, 5, want_stats=True)
     assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
+
+
+# ------------------------------------------------------------------ canvas quantise + PPM encode on the device
+def _device_ppm(world, rgb):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(rgb)).to("cuda:0")
+    q = torch.zeros(rgb.shape, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    text = rt.canvas_to_ppm_device(world.scene(), t.data_ptr(), rgb.shape[1], rgb.shape[0], q.data_ptr())
+    return text, q.cpu().numpy()
+
+
+def test_device_ppm_reference_kats():  # canvas.rs:136-200
+    w = World.default()
+    rgb = np.zeros((3, 5, 3))
+    rgb[0, 0] = (1.5, 0., 0.)
+    rgb[1, 2] = (0., 0.5, 0.)
+    rgb[2, 4] = (-0.5, 0., 1.)
+    text, q = _device_ppm(w, rgb)
+    lines = text.decode().splitlines()
+    assert lines[:3] == ["P3", "5 3", "255"]
+    assert lines[3:6] == ["255 0 0 0 0 0 0 0 0 0 0 0 0 0 0", "0 0 0 0 0 0 0 128 0 0 0 0 0 0 0", "0 0 0 0 0 0 0 0 0 0 0 0 0 0 255"]
+    rgb = np.zeros((2, 10, 3))
+    rgb[:, :] = (1., 0.8, 0.6)
+    text, _ = _device_ppm(w, rgb)
+    lines = text.decode().splitlines()
+    assert lines[3] == "255 204 153 255 204 153 255 204 153 255 204 153 255 204 153 255 204"
+    assert lines[4] == "153 255 204 153 255 204 153 255 204 153 255 204 153"
+    assert lines[5] == lines[3] and lines[6] == lines[4] and text.endswith(b"\n")
+
+
+def test_device_ppm_is_byte_identical_to_the_host_mirror():
+    w = World.default()
+    rng = np.random.default_rng(5)
+    for shape in ((1, 1), (7, 23), (33, 24), (50, 301)):
+        rgb = rng.uniform(-0.2, 1.2, size=shape + (3,))
+        rgb[rng.uniform(size=shape) < 0.02] = np.nan
+        rgb[rng.uniform(size=shape) < 0.05] = (0.5 / 255., 1.5 / 255., 2.5 / 255.)   # exact halves: round away from zero
+        rgb[0, 0] = (-0., 1., 1. + 1e-16)
+        text, q = _device_ppm(w, rgb)
+        host = rt.Image(rgb, None, None, None).to_ppm()
+        assert text == host.encode()
+        assert np.array_equal(q, rt.Image(rgb, None, None, None).quantised().astype(np.uint8))
+        assert all(len(l) <= 69 for l in text.decode().splitlines())
+    # a rendered frame end to end
+    world, cam = scenes.book_world(160, 80)
+    img = cam.render(world)
+    text, _ = _device_ppm(world, img.rgb)
+    assert text == img.to_ppm().encode()
