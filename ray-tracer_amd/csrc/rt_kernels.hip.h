@@ -1183,24 +1183,39 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {  // shadow queue, container queue
-        const int q = threadIdx.x;
-        int run = 0;
-        for (int it = 0; it < TILE_ITERS; ++it)
-            for (int w = 0; w < BLOCK / 64; ++w) { int c = ts.off[q][it][w]; ts.off[q][it][w] = run; run += c; }
-        ts.base[q] = run ? (long long)atomicAdd(counters + (q == 0 ? CNT_SHADOW_Q : CNT_CONTAINER_Q), (unsigned long long)run) : 0;
-    } else if (threadIdx.x == 64) {  // both ray kinds share the next level's queue: reflection rays of a wavefront first
-        int run = 0, n_refl = 0, n_refr = 0;
-        for (int it = 0; it < TILE_ITERS; ++it)
-            for (int w = 0; w < BLOCK / 64; ++w) {
-                int c0 = ts.off[2][it][w], c1 = ts.off[3][it][w];
-                ts.off[2][it][w] = run; run += c0;
-                ts.off[3][it][w] = run; run += c1;
-                n_refl += c0; n_refr += c1;
+    // exclusive scans of the per-(iteration, wavefront) counts, one wavefront per queue (a single thread walking the
+    // 128 entries through LDS cost ~10 us per tile): lane l owns entries 2l and 2l+1
+    {
+        constexpr int PER = TILE_ITERS * (BLOCK / 64) / 64;  // entries per lane
+        static_assert(PER == 2, "k_queue's scan assumes 128 entries per queue");
+        int* flat0 = &ts.off[0][0][0];
+        auto wave_exclusive = [&](int v) {  // exclusive prefix sum over the wavefront; returns (prefix, total via reference)
+            int inc = v;
+            for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+            return inc - v;
+        };
+        if (wave < 2) {  // shadow queue, container queue
+            int* f = flat0 + wave * TILE_ITERS * (BLOCK / 64);
+            const int c0 = f[2 * lane], c1 = f[2 * lane + 1];
+            const int pre = wave_exclusive(c0 + c1);
+            f[2 * lane] = pre; f[2 * lane + 1] = pre + c0;
+            const int total = __shfl(pre + c0 + c1, 63, 64);
+            if (lane == 0) ts.base[wave] = total ? (long long)atomicAdd(counters + (wave == 0 ? CNT_SHADOW_Q : CNT_CONTAINER_Q), (unsigned long long)total) : 0;
+        } else if (wave == 2) {  // both ray kinds share the next level's queue: reflection rays of a wavefront first
+            int* f2 = flat0 + 2 * TILE_ITERS * (BLOCK / 64);
+            int* f3 = flat0 + 3 * TILE_ITERS * (BLOCK / 64);
+            const int a0 = f2[2 * lane], b0 = f3[2 * lane], a1 = f2[2 * lane + 1], b1 = f3[2 * lane + 1];
+            const int pre = wave_exclusive(a0 + b0 + a1 + b1);
+            f2[2 * lane] = pre; f3[2 * lane] = pre + a0; f2[2 * lane + 1] = pre + a0 + b0; f3[2 * lane + 1] = pre + a0 + b0 + a1;
+            const int total = __shfl(pre + a0 + b0 + a1 + b1, 63, 64);
+            int n_refl = a0 + a1, n_refr = b0 + b1;
+            for (int off = 32; off > 0; off >>= 1) { n_refl += __shfl_xor(n_refl, off, 64); n_refr += __shfl_xor(n_refr, off, 64); }
+            if (lane == 0) {
+                ts.base[2] = total ? (long long)atomicAdd(counters + CNT_NEXT, (unsigned long long)total) : 0;
+                if (n_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)n_refl);
+                if (n_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)n_refr);
             }
-        ts.base[2] = run ? (long long)atomicAdd(counters + CNT_NEXT, (unsigned long long)run) : 0;
-        if (n_refl) atomicAdd(counters + CNT_REFLECT, (unsigned long long)n_refl);
-        if (n_refr) atomicAdd(counters + CNT_REFRACT, (unsigned long long)n_refr);
+        }
     }
     __syncthreads();
 #pragma unroll
