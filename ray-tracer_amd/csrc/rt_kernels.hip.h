@@ -90,11 +90,14 @@ struct ClosestSink {
     double first_t, fu, fv;
     int first_key, first_uv;
     unsigned flags;
+    double stop_below;  // the search may end as soon as a hit with t below this is known (-inf: never)
     __device__ __forceinline__ void init(double tmax) {
         best_t = tmax; best_key = -1; bu = bv = 0.;
         first_t = INFINITY; first_key = -1; fu = fv = 0.; first_uv = 0;
         flags = 0;
+        stop_below = -INFINITY;
     }
+    __device__ __forceinline__ bool done() const { return best_t < stop_below; }
     __device__ __forceinline__ double lo() const { return NEED_FIRST ? -INFINITY : 0.; }
     __device__ __forceinline__ double hi() const { return best_t; }
     __device__ __forceinline__ void emit(double t, int key, double u, double v, int uv) {
@@ -110,6 +113,7 @@ struct ClosestSink {
 
 // Everything with t <= limit or near_eq(t, limit), kept as an unsorted bounded list (sorted by the caller).
 struct ListSink {
+    __device__ __forceinline__ bool done() const { return false; }
     double* t;    // [LIST_CAP], private
     int* key;
     int n;        // true count (may exceed cap)
@@ -513,7 +517,7 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth);
             }
         }
-        if (sp == 0) break;
+        if (sp == 0 || sink.done()) break;
         cur = stack_pop(M, --sp);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -588,6 +592,7 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
             it.a = q->a; it.b = q->b; it.op = q->op; it.chain_len = q->chain_len;
             it.x0 = q->x0; it.x1 = q->x1; it.chain = q->chain; it.p0 = q->p0; it.p1 = q->p1;
         }
+        if (sink.done()) until = n_items;  // an any-hit search that has its answer sleeps through the rest
         const bool on = i >= until;
         ++i;
         if (it.type == ITEM_CSG_BEGIN) {
@@ -995,6 +1000,9 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V
     ClosestSink<false> sink;
     // hits at t >= distance cannot shadow and cannot displace a nearer hit: bound the search there
     sink.init(distance);
+    // F8: the answer is `nearest.t < distance && nearest.casts_shadow`.  When EVERY leaf of the scene casts shadows that
+    // is "some hit has 0 < t < distance", and the first such hit ends the search; otherwise the nearest must be found.
+    if (S.all_cast_shadow) sink.stop_below = distance;
     traverse<HAS_CSG, COUNT>(S, M, point, direction, sink, w, alive);
     flags |= sink.flags;
     if (sink.best_key < 0) return false;
