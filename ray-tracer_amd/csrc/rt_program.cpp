@@ -485,7 +485,22 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err) {
     // chain 0 = the empty chain
     c.chain_offset({});
     out.node_nchain.assign(size_t(d.n_nodes), -1);
-    for (int32_t n = 0; n < d.n_nodes; n = d.node_subtree_end[n]) c.emit(n, {});
+    // Emission order of the top-level objects is free (results are ordered by (t, node key), not by visit order): the
+    // ones without a triangle mesh go first, so that by the time a ray reaches a mesh its closest-hit bound — which
+    // prunes the mesh box and the BVH — already knows about the cheap primitives.
+    auto has_mesh = [&](int32_t root) {
+        for (int32_t g = root; g < d.node_subtree_end[root]; ++g) {
+            if (d.node_kind[g] != RT_GROUP) continue;
+            size_t tris = 0;
+            for (int32_t ch = g + 1; ch < d.node_subtree_end[g]; ch = d.node_subtree_end[ch])
+                if ((d.node_kind[ch] == RT_TRIANGLE || d.node_kind[ch] == RT_SMOOTH_TRIANGLE) && d.node_xform[ch] == 0) ++tris;
+            if (tris >= size_t(MESH_MIN_TRIANGLES)) return true;
+        }
+        return false;
+    };
+    for (int pass = 0; pass < 2; ++pass)
+        for (int32_t n = 0; n < d.n_nodes; n = d.node_subtree_end[n])
+            if (has_mesh(n) == (pass == 1)) c.emit(n, {});
     for (int32_t n = 0; n < d.n_nodes; ++n) {
         int32_t k = d.node_kind[n];
         if (k <= RT_SMOOTH_TRIANGLE) {
