@@ -629,6 +629,12 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     UP(upload(s, vec_of(d.node_eq_class, size_t(d.n_nodes)), &s->ds.node_eq_class));
     UP(upload(s, vec_of(d.node_param, size_t(d.n_nodes)), &s->ds.node_param));
     UP(upload(s, prog.node_nchain, &s->ds.node_nchain));
+    {
+        std::vector<NodeRec> recs(size_t(d.n_nodes));
+        for (size_t n = 0; n < recs.size(); ++n)
+            recs[n] = NodeRec{d.node_kind[n], d.node_param[n], prog.node_nchain[n], d.node_material[n]};
+        UP(upload(s, recs, &s->ds.node_rec));
+    }
     UP(upload(s, vec_of(d.node_casts_shadow, size_t(d.n_nodes)), &s->ds.node_casts_shadow));
     UP(upload(s, rows3(d.xform_inverse, d.n_xforms), &s->ds.xf));
     UP(upload(s, vec_of(d.group_box, size_t(d.n_groups) * 6), &s->ds.group_box));

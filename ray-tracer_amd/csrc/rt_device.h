@@ -14,14 +14,23 @@ constexpr int LDS_STACK = 12;     // traversal stack entries per lane kept in LD
 constexpr int LDS_NODE_CAP = 895; // BVH4 nodes staged in LDS: ~112 KiB + 48 KiB of per-lane stacks + the feed word <= 160 KiB
 constexpr int FEED_PARTS = 8;     // chunk-feed counters per traversal kernel, one cache line each
 constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
+constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
 constexpr int LIST_CAP = 64;      // per-ray list for the n1/n2 container walk and rt_intersect_world
 constexpr int CONTAINER_CAP = 32; // `containers` vector of prepare_computations
 constexpr int MAX_CHAIN = 16;     // transform levels above a leaf
 
+// What prepare_computations needs to know about the hit node, in one 16-byte fetch (the SoA columns below stay for
+// the kernels that need a single field).
+struct NodeRec {
+    int32_t kind, param, nchain, material;
+};
+static_assert(sizeof(NodeRec) == 16, "NodeRec must be 16 bytes");
+
 // Scene tables in HBM.  SoA per table; rows padded to what one lane fetches at once.
 struct DScene {
+    const NodeRec* node_rec;
     // nodes (src/shape.rs:25-37)
     const int32_t* node_kind;
     const int32_t* node_object_id;

@@ -666,7 +666,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
             double tnear;
             bump<COUNT>(w.box);
             if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo(), sink.hi(), tnear))
+            {
                 bvh_traverse<COUNT>(S, M, it.a, o, d, inv, sink, full_line, w, out);
+            }
             continue;
         }
         // ITEM_LEAF
@@ -706,7 +708,8 @@ struct FeedShared {
 struct Feed {
     unsigned long long* cnt;
     RT_LDS FeedShared* sh;
-    long long n_chunks;
+    long long n_chunks;               // positions handed out (n_real rounded up to a multiple of FEED_ROWS)
+    long long n_real, cols;           // chunks that exist; positions per row of the scatter below
     long long next_static, stride_static;
 
     // one lane: next batch as a packed word, or the end mark
@@ -737,12 +740,14 @@ struct Feed {
     __device__ __forceinline__ void init(unsigned long long* counters, long long chunks, RT_LDS FeedShared* shared) {
         cnt = counters;
         sh = shared;
-        n_chunks = chunks;
+        n_real = chunks;
+        cols = (chunks + FEED_ROWS - 1) / FEED_ROWS;
+        n_chunks = cols * FEED_ROWS;
         const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
         next_static = wave;
         stride_static = (long long)gridDim.x * (TBLOCK / 64);
         // a launch with at most two chunks per wavefront has nothing to balance: deal statically, no atomics at all
-        if (n_chunks <= 2 * stride_static) cnt = nullptr;
+        if (n_real <= 2 * stride_static) cnt = nullptr;
         if (cnt && threadIdx.x == 0) {
             sh->part = int(blockIdx.x % FEED_PARTS);
             sh->dry = 0;
@@ -753,7 +758,21 @@ struct Feed {
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return ((unsigned long long)hi << 32) | lo;
     }
+    // Expensive rays come in clumps (the tiles that see a mesh, the shadow they cast), and so do the positions a
+    // workgroup's batch or a wavefront's static share covers.  Position p therefore stands for chunk
+    // (p % FEED_ROWS) * cols + p / FEED_ROWS: consecutive positions are a FEED_ROWS-th of the level apart, every batch
+    // samples the whole level, and a clump of heavy chunks is spread over all compute units instead of queueing up
+    // on the SIMDs of a few.  (Measured before: wavefront lifetimes within one launch ranged from 130k to over 1M
+    // cycles.)  Positions past the last chunk are skipped.
     __device__ __forceinline__ long long next() {  // -1: nothing left
+        while (true) {
+            const long long p = next_position();
+            if (p < 0) return -1;
+            const long long c = (p % FEED_ROWS) * cols + p / FEED_ROWS;
+            if (c < n_real) return c;
+        }
+    }
+    __device__ __forceinline__ long long next_position() {
         if (!cnt) {
             long long c = next_static;
             next_static += stride_static;
@@ -871,23 +890,18 @@ __global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long 
 // ---------------------------------------------------------------------------------------------------------
 // Shading: prepare_computations, is_shadowed, lighting, ray spawn.
 
-// Shape::normal_at (src/shape.rs:92-108): world_to_object down the registry chain, local normal, normal_to_world up.
+// Shape::normal_at (src/shape.rs:92-108): world_to_object down the registry chain, local normal, normal_to_world up
+// (normal_at_wave below; world_to_object alone also serves Pattern::pattern_at_shape).
 __device__ __forceinline__ V3 world_to_object(const DScene& S, int node, V3 p) {  // src/shape.rs:394-404
     const int* __restrict__ c = S.chain_pool + S.node_nchain[node];
     for (int k = c[0]; k >= 1; --k)  // outermost ancestor first
         if (c[k] != 0) p = xf_point(S.xf + (size_t)c[k] * 12, p);
     return p;
 }
-__device__ __forceinline__ V3 normal_to_world(const DScene& S, int node, V3 n) {  // src/shape.rs:406-420
-    const int* __restrict__ c = S.chain_pool + S.node_nchain[node];
-    for (int k = 1; k <= c[0]; ++k) {
-        if (c[k] != 0) n = xf_normal(S.xf + (size_t)c[k] * 12, n);
-        n = normalize(n);  // every level normalises, identity or not
-    }
-    return n;
-}
-
-__device__ __forceinline__ V3 local_normal_at(const DScene& S, int node, int kind, V3 p, double hu, double hv) {
+// Local normals (each kind's normal_at).  What they need from memory besides the point arrives as arguments, so that
+// the caller can request it ahead of time: `tri_n` = the flat triangle's stored normal, `cmin`/`cmax` = conic limits.
+__device__ __forceinline__ V3 local_normal_at(const DScene& S, int kind, int param, V3 p, double hu, double hv, V3 tri_n, double cmin,
+                                              double cmax) {
     switch (kind) {
         case RT_SPHERE: return p;               // point - ORIGIN, src/sphere.rs:65-67
         case RT_PLANE: return mk(0., 1., 0.);   // src/plane.rs:53-56
@@ -898,16 +912,14 @@ __device__ __forceinline__ V3 local_normal_at(const DScene& S, int node, int kin
             else return mk(0., 0., p.z);
         }
         case RT_CYLINDER: {  // src/cylinder.rs:113-127
-            int q = S.node_param[node];
-            double minimum = S.conic[2 * q], maximum = S.conic[2 * q + 1];
+            double minimum = cmin, maximum = cmax;
             double distance = p.x * p.x + p.z * p.z;
             if (distance < 1. && (p.y > maximum - EPS || near_eq(p.y, maximum - EPS))) return mk(0., 1., 0.);
             else if (distance < 1. && (p.y < minimum + EPS || near_eq(p.y, minimum + EPS))) return mk(0., -1., 0.);
             else return mk(p.x, 0., p.z);
         }
         case RT_CONE: {  // src/cone.rs:119-135
-            int q = S.node_param[node];
-            double minimum = S.conic[2 * q], maximum = S.conic[2 * q + 1];
+            double minimum = cmin, maximum = cmax;
             double distance = p.x * p.x + p.z * p.z;
             if (distance < maximum * maximum && (p.y > maximum - EPS || near_eq(p.y, maximum - EPS))) return mk(0., 1., 0.);
             else if (distance < minimum * minimum && (p.y < minimum + EPS || near_eq(p.y, minimum + EPS))) return mk(0., -1., 0.);
@@ -916,16 +928,62 @@ __device__ __forceinline__ V3 local_normal_at(const DScene& S, int node, int kin
                 return mk(p.x, p.y > 0. ? -y : y, p.z);
             }
         }
-        case RT_TRIANGLE: {  // src/triangle.rs:89-91
-            const double* __restrict__ t = S.tri + (size_t)S.node_param[node] * 12;
-            return mk(t[9], t[10], t[11]);
-        }
+        case RT_TRIANGLE: return tri_n;  // src/triangle.rs:89-91
         default: {  // RT_SMOOTH_TRIANGLE, src/smooth_triangle.rs:98-104
-            const double* __restrict__ s = S.smooth + (size_t)S.tri_smooth[S.node_param[node]] * 9;
+            const double* __restrict__ s = S.smooth + (size_t)S.tri_smooth[param] * 9;
             V3 n1 = mk(s[0], s[1], s[2]), n2 = mk(s[3], s[4], s[5]), n3 = mk(s[6], s[7], s[8]);
             return vadd(vadd(vmul(n2, hu), vmul(n3, hv)), vmul(n1, (1. - hu - hv)));
         }
     }
+}
+
+// Shape::normal_at for the hits of one wavefront (k_trace's epilogue).  Lanes of a wavefront hit a handful of distinct
+// transform chains (all triangles of a mesh share one), so the chains are walked one at a time with the chain and its
+// matrices fetched by scalar loads: a lane-private walk costs a dependent vector-load round trip per chain entry and
+// per matrix (node -> chain offset -> length -> entry -> 12 matrix elements, twice), which made prepare_computations
+// the longest part of a chunk.  Arithmetic and its order are those of world_to_object / normal_to_world above.
+__device__ __forceinline__ V3 normal_at_wave(const DScene& S, bool hit, const NodeRec& rec, V3 world_point, double hu, double hv) {
+    // what the local normal needs from memory, requested before the chain walk so that it arrives meanwhile
+    V3 tri_n = mk(0., 0., 0.);
+    double cmin = 0., cmax = 0.;
+    if (hit && rec.kind == RT_TRIANGLE) {
+        const double* __restrict__ t = S.tri + (size_t)rec.param * 12;
+        tri_n = mk(t[9], t[10], t[11]);
+    } else if (hit && (rec.kind == RT_CYLINDER || rec.kind == RT_CONE)) {
+        cmin = S.conic[2 * rec.param];
+        cmax = S.conic[2 * rec.param + 1];
+    }
+    const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);
+    const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
+    V3 result = mk(0., 0., 0.);
+    bool pending = hit;
+    while (true) {
+        const unsigned long long m = __ballot(pending);
+        if (!m) break;
+        const int cid = __builtin_amdgcn_readlane(rec.nchain, __ffsll((long long)m) - 1);
+        // The compiler must not learn that the address below equals the lane's own rec.nchain inside the branch (it
+        // would substitute the per-lane value and fall back to vector loads): the address uses an opaque scalar copy.
+        int cid_scalar = cid;
+        asm volatile("" : "+s"(cid_scalar));
+        if (pending && rec.nchain == cid) {
+            const RT_CONSTANT int32_t* __restrict__ c = pool + cid_scalar;  // [len, x_leaf, x_parent, ..., x_root]
+            const int len = c[0];
+            V3 p = world_point;
+            for (int k = len; k >= 1; --k) {  // world_to_object, outermost ancestor first (src/shape.rs:394-404)
+                const int x = c[k];
+                if (x != 0) p = xf_point(xf + (size_t)x * 12, p);
+            }
+            V3 n = local_normal_at(S, rec.kind, rec.param, p, hu, hv, tri_n, cmin, cmax);
+            for (int k = 1; k <= len; ++k) {  // normal_to_world (src/shape.rs:406-420): every level normalises
+                const int x = c[k];
+                if (x != 0) n = xf_normal(xf + (size_t)x * 12, n);
+                n = normalize(n);
+            }
+            result = n;
+            pending = false;
+        }
+    }
+    return result;
 }
 
 __device__ __forceinline__ int as_i32(double x) {  // Rust `as i32`: saturating, NaN -> 0
@@ -1085,14 +1143,14 @@ constexpr int ST_TIR = 16;       // ... but total internal reflection (src/world
 
 __device__ __forceinline__ unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
-__device__ __forceinline__ bool needs_walk(const DScene& S, const double* __restrict__ m, int remaining) {
+__device__ __forceinline__ bool needs_walk(const DScene& S, double reflective, double transparency, int remaining) {
     // n1/n2 are read only by refracted_color and schlick, both behind a transparency test.  At remaining <= 0
     // refracted_color and reflected_color return BLACK before using them (src/world.rs:110,121) and schlick's result
     // only scales those two BLACKs: any FINITE reflectance gives surface + 0 + 0.  It is finite whenever every
     // refractive index in the scene is finite and positive (S.walk_at_zero == 0), so the walk is skipped there and
     // k_finish records reflectance 0.
     if (remaining <= 0 && !S.walk_at_zero) return false;
-    return !near_eq(m[RT_MAT_TRANSPARENCY], 0.) || (m[RT_MAT_REFLECTIVE] > 0. && m[RT_MAT_TRANSPARENCY] > 0.);
+    return !near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.);
 }
 
 // Ray count of a level: known to the host (`n_dev` == null), or — when a whole frame is enqueued without a host
@@ -1111,49 +1169,70 @@ __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n
     Feed feed;
     const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
     Work w = {};
-    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+    // A chunk's rays are requested one chunk ahead (just before the previous chunk's epilogue, whose dependent look-ups
+    // they overlap): a wavefront is one of four on its SIMD, so nothing else hides that round trip.
+    auto fetch = [&](long long c, V3& o, V3& d) {
         const long long i = c * 64 + (threadIdx.x & 63);
-        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        bool alive = false;
-        if (i < n) {
+        o = mk(NAN, 0., 0.);  // NaN origin = padding slot / dead ray
+        d = mk(0., 0., 1.);
+        if (c >= 0 && i < n) {
             o = mk(L.ox[i], L.oy[i], L.oz[i]);
             d = mk(L.dx[i], L.dy[i], L.dz[i]);
-            alive = o.x == o.x;  // NaN origin = padding slot / dead ray
         }
+    };
+    long long c = feed.next();
+    V3 o, d;
+    fetch(c, o, d);
+    while (c >= 0) {
+        const long long i = c * 64 + (threadIdx.x & 63);
+        const bool alive = o.x == o.x;
+        if (!alive) o = mk(0., 0., 0.);
         ClosestSink<NEED_FIRST> sink;
         sink.init(INFINITY);
         traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
-        if (i >= n) continue;
-        int stage = 0;
-        unsigned flags = 0;
+        const long long c_next = feed.next();
+        V3 o_next, d_next;
+        fetch(c_next, o_next, d_next);
+        // ---- epilogue: prepare_computations (src/intersection.rs:38-48) for the lanes that hit something
         const int key = alive ? sink.best_key : -1;
-        if (key >= 0) {
-            const int node = key >> 2;
-            const int kind = S.node_kind[node];
-            double u = sink.bu, v = sink.bv;
-            flags = sink.flags;
-            if (NEED_FIRST && kind == RT_SMOOTH_TRIANGLE) {
-                if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
-                else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
-            }
-            // prepare_computations, src/intersection.rs:38-48
-            V3 point = vadd(o, vmul(d, sink.best_t));  // Ray::position
-            V3 local_point = world_to_object(S, node, point);
-            V3 normal_vector = normal_to_world(S, node, local_normal_at(S, node, kind, local_point, u, v));
-            V3 eye_vector = vneg(d);
+        const bool hit = key >= 0;
+        const int node = hit ? key >> 2 : 0;
+        NodeRec rec = {0, 0, 0, 0};
+        if (hit) rec = S.node_rec[node];
+        double reflective = 0., transparency = 0.;
+        if (hit) {
+            const double* __restrict__ m = S.mat + (size_t)rec.material * RT_MAT_STRIDE;
+            reflective = m[RT_MAT_REFLECTIVE];
+            transparency = m[RT_MAT_TRANSPARENCY];
+        }
+        double u = sink.bu, v = sink.bv;
+        unsigned flags = hit ? sink.flags : 0;
+        if (NEED_FIRST && hit && rec.kind == RT_SMOOTH_TRIANGLE) {
+            if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+            else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+        }
+        const V3 point = vadd(o, vmul(d, sink.best_t));  // Ray::position
+        V3 normal_vector = normal_at_wave(S, hit, rec, point, u, v);
+        int stage = 0;
+        if (hit) {
+            const V3 eye_vector = vneg(d);
             if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
             L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
             L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
             L.ht[i] = sink.best_t;
-            const double* __restrict__ m = S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE;
             stage = ST_HIT;
-            if (needs_walk(S, m, remaining)) stage |= ST_WALK;
-            if (!(near_eq(m[RT_MAT_REFLECTIVE], 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
-            if (!(near_eq(m[RT_MAT_TRANSPARENCY], 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
+            if (needs_walk(S, reflective, transparency, remaining)) stage |= ST_WALK;
+            if (!(near_eq(reflective, 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
+            if (!(near_eq(transparency, 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
         }
-        L.hkey[i] = key;
-        L.mode[i] = stage;
-        L.flags[i] = (uint8_t)flags;
+        if (i < n) {
+            L.hkey[i] = key;
+            L.mode[i] = stage;
+            L.flags[i] = (uint8_t)flags;
+        }
+        c = c_next;
+        o = o_next;
+        d = d_next;
     }
     if (COUNT) flush_work(w, counters);
 }

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libraytracer_amd.so")  # RT_AMD_LIB: experiment builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; there is no fallback path")
 lib = C.CDLL(LIB_PATH)
