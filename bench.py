@@ -5,7 +5,8 @@ Workload (BASELINE.json metric: "Mrays/sec + ms/frame, teapot.obj 1920x1080 dept
 reference parser loads it (6320 flat triangles) + glass sphere + mirror sphere + checkered reflective floor, one
 light, 1920x1080, depth 5 (tests/scenes.py:teapot_scene).  One "step" = one frame = Camera::render over the whole
 (hsize-1)x(vsize-1) pixel domain.  Scene tables are resident in HBM before the timed region; each step ends with the
-frame assembled in device memory on rank 0 (N > 1: shards gathered with RCCL over xGMI, then scattered).
+frame assembled in device memory on rank 0 (N = 1: rt_render_frame writes the row-major frame directly; N > 1:
+shards gathered with RCCL over xGMI, then scattered by rt_assemble).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -141,6 +142,13 @@ def main():
     opts = rt.RenderOpts(max_depth=args.depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
 
     def step(stats=None):
+        if world == 1:
+            # one GPU: Camera::render straight into the row-major frame in HBM (rt_render_frame), one blocking call
+            rc = rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None,
+                                        C.byref(stats) if stats is not None else None)
+            if rc < 0:
+                raise RuntimeError(rt.last_error())
+            return
         rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shard.data_ptr(), None, None,
                                     C.byref(stats) if stats is not None else None)
         if rc < 0:

@@ -264,6 +264,14 @@ int64_t rt_shard_pixel_count(const rt_camera_desc* camera, int32_t rank, int32_t
 int rt_render_shard(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_out,
                     int32_t* d_hit_id_out, uint8_t* d_flags_out, rt_stats* stats_out);
 
+/* Camera::render (src/camera.rs:62-74) with the Canvas left in DEVICE memory: d_rgb_frame [vsize*hsize*3] row-major
+ * (Canvas::write_pixel layout, src/canvas.rs:25-27), d_hit_id_frame / d_flags_frame nullable [vsize*hsize].  The
+ * pixels of shard opts->rank of opts->n_ranks are written where they belong in the frame, the never-rendered last row
+ * and column (F1) are cleared, everything else is left alone: with n_ranks == 1 this is the whole render, one call and
+ * no intermediate copy; ranks of one process may also fill one frame in turn.  Blocking unless opts->stream is set. */
+int rt_render_frame(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_frame,
+                    int32_t* d_hit_id_frame, uint8_t* d_flags_frame, rt_stats* stats_out);
+
 /* Scatter gathered shards (concatenated in rank order, DEVICE memory, on `scene`'s device) into a full
  * row-major frame, zero elsewhere.  d_rgb_frame [vsize*hsize*3] device.  d_hit_id_* nullable. */
 int rt_assemble(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const double* d_rgb_shards,

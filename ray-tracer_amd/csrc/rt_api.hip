@@ -449,7 +449,7 @@ int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams
 }
 
 int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb,
-                      int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots) {
+                      int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots, bool frame = false) {
     long long n_valid = 0;
     int rc = camera_params(cam, opts->rank, opts->n_ranks, c, n_slots, n_valid);
     if (rc != RT_OK) return rc;
@@ -480,7 +480,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
         put(cam, sizeof *cam); put(&opts->rank, sizeof opts->rank); put(&opts->n_ranks, sizeof opts->n_ranks);
         put(&D, sizeof D); put(&K, sizeof K); put(&d_rgb, sizeof d_rgb); put(&d_id, sizeof d_id); put(&d_flags, sizeof d_flags);
-        put(&st, sizeof st);
+        put(&st, sizeof st); put(&frame, sizeof frame);
         for (int k = 0; k < K; ++k) {
             ChainScope scope(s, k);
             for (int d = 0; d <= D && size_t(d) < s->levels.size(); ++d) { put(&s->levels[size_t(d)].block, sizeof(void*)); put(&s->levels[size_t(d)].cap, sizeof(long long)); }
@@ -493,7 +493,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
             hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, ck[k], s->levels[0].L, nk[k]);
             int rc2 = enqueue_levels_async(s, sk, nk[k], D);
             if (rc2 != RT_OK) return rc2;
-            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k);
+            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k, ck[k], frame ? 1 : 0);
             HIP_TRY(hipEventRecord(s->parked[k].done, sk));
             return RT_OK;
         };
@@ -554,7 +554,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
             hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, ck[k], s->levels[0].L, nk[k]);
             rc = run_levels(s, st, nk[k], D, false, nullptr);
             if (rc != RT_OK) return rc;
-            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k);
+            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k, ck[k], frame ? 1 : 0);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));
         }
@@ -574,7 +574,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     tm.end();
     rc = run_levels(s, st, n_slots, opts->max_depth, opts->want_counters != 0, stats);
     if (rc != RT_OK) return rc;
-    hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0);
+    hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(e1, st));
@@ -788,6 +788,33 @@ int rt_render_shard(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
     return RT_OK;
 }
 
+int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
+                    uint8_t* d_flags_frame, rt_stats* stats) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !d_rgb_frame || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = opts->stream ? static_cast<hipStream_t>(opts->stream) : s->stream;
+    // Canvas::new is all BLACK and Camera::render never writes the last row and column (F1): those are the only
+    // pixels of the frame no shard owns, so they are the only ones cleared here.
+    const size_t W = size_t(cam->hsize), H = size_t(cam->vsize);
+    HIP_TRY(hipMemsetAsync(d_rgb_frame + (H - 1) * W * 3, 0, W * 3 * sizeof(double), st));
+    HIP_TRY(hipMemset2DAsync(d_rgb_frame + (W - 1) * 3, W * 3 * sizeof(double), 0, 3 * sizeof(double), H, st));
+    if (d_hit_id_frame) {
+        HIP_TRY(hipMemsetAsync(d_hit_id_frame + (H - 1) * W, 0, W * sizeof(int32_t), st));
+        HIP_TRY(hipMemset2DAsync(d_hit_id_frame + (W - 1), W * sizeof(int32_t), 0, sizeof(int32_t), H, st));
+    }
+    if (d_flags_frame) {
+        HIP_TRY(hipMemsetAsync(d_flags_frame + (H - 1) * W, 0, W, st));
+        HIP_TRY(hipMemset2DAsync(d_flags_frame + (W - 1), W, 0, 1, H, st));
+    }
+    CameraParams c;
+    long long n_slots = 0;
+    int rc = render_shard_impl(s, cam, opts, st, d_rgb_frame, d_hit_id_frame, d_flags_frame, stats, c, n_slots, true);
+    if (rc != RT_OK) return rc;
+    if (!opts->stream) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
 int rt_assemble(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const double* d_rgb_shards, const int32_t* d_id_shards,
                 double* d_rgb_frame, int32_t* d_id_frame, void* stream) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
@@ -822,24 +849,16 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     if (n_slots < 0) { rt_set_error("bad camera size or shard"); return RT_ERR_BAD_ARG; }
     size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
     int rc;
-    if ((rc = grow(s->out_rgb, size_t(n_slots) * 3 * sizeof(double))) != RT_OK) return rc;
-    if ((rc = grow(s->out_id, size_t(n_slots) * sizeof(int32_t))) != RT_OK) return rc;
-    if ((rc = grow(s->out_flags, size_t(n_slots))) != RT_OK) return rc;
     if ((rc = grow(s->frame_rgb, npx * 3 * sizeof(double))) != RT_OK) return rc;
     if ((rc = grow(s->frame_id, npx * sizeof(int32_t))) != RT_OK) return rc;
     if ((rc = grow(s->frame_flags, npx)) != RT_OK) return rc;
-    CameraParams c;
-    rc = render_shard_impl(s, cam, opts, st, static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p),
-                           static_cast<uint8_t*>(s->out_flags.p), stats, c, n_slots);
-    if (rc != RT_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->frame_rgb.p, 0, npx * 3 * sizeof(double), st));  // Canvas::new: all BLACK
     HIP_TRY(hipMemsetAsync(s->frame_id.p, 0, npx * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(s->frame_flags.p, 0, npx, st));
-    if (n_slots)
-        hipLaunchKernelGGL(k_assemble, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, static_cast<const double*>(s->out_rgb.p),
-                           static_cast<const int32_t*>(s->out_id.p), static_cast<const uint8_t*>(s->out_flags.p),
-                           static_cast<double*>(s->frame_rgb.p), static_cast<int32_t*>(s->frame_id.p), static_cast<uint8_t*>(s->frame_flags.p));
-    HIP_TRY(hipGetLastError());
+    CameraParams c;
+    rc = render_shard_impl(s, cam, opts, st, static_cast<double*>(s->frame_rgb.p), static_cast<int32_t*>(s->frame_id.p),
+                           static_cast<uint8_t*>(s->frame_flags.p), stats, c, n_slots, true);  // straight into the frame
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->frame_rgb.p, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->frame_id.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->frame_flags.p, npx, hipMemcpyDeviceToHost, st));
@@ -902,7 +921,8 @@ int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double
     rc = run_levels(s, st, n_rays, remaining, false, stats);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(k_output, dim3(blocks_for(n_rays)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, (long long)n_rays,
-                       static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p), static_cast<uint8_t*>(s->out_flags.p), 1, 0);
+                       static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p), static_cast<uint8_t*>(s->out_flags.p), 1, 0,
+                       CameraParams{}, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rgb_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
     if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->out_id.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -1485,11 +1485,18 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n
 // scatter into the full row-major frame (Canvas layout, src/canvas.rs:25-27).
 // `chains` > 1: this level holds sub-shard `chain` of the shard (every chains-th 8x8 tile); its 64-slot tiles are
 // written to their interleaved places in the shard buffer.
+// `frame` != 0: the outputs are whole row-major frames (Canvas layout) and slot i goes to its pixel — `cam` is the
+// camera of the (sub-)shard this level holds; padding slots write nothing.
 __global__ __launch_bounds__(BLOCK) void k_output(DScene S, Level L, long long n, double* rgb, int32_t* hit_id, uint8_t* flags,
-                                                  int chains, int chain) {
+                                                  int chains, int chain, CameraParams cam, int frame) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const long long o = ((i >> 6) * chains + chain) * 64 + (i & 63);
+    long long o = ((i >> 6) * chains + chain) * 64 + (i & 63);
+    if (frame) {
+        int px, py;
+        if (!slot_to_pixel(cam, i, px, py)) return;
+        o = (long long)py * cam.hsize + px;
+    }
     rgb[3 * o] = L.cr[i]; rgb[3 * o + 1] = L.cg[i]; rgb[3 * o + 2] = L.cb[i];
     if (hit_id) {
         int key = L.hkey[i];

@@ -315,6 +315,31 @@ def test_device_shard_path_matches_host_path():
     assert np.array_equal(host, full.rgb)
 
 
+def test_render_frame_writes_the_canvas_in_device_memory():
+    """rt_render_frame: Camera::render with the row-major Canvas left in HBM.  Whole frame in one call, two shards
+    filling one frame in turn, the large (chained, graph-replayed) path twice in a row — all equal to rt_render,
+    and the never-rendered last row / column (F1) cleared even when the buffer held garbage."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for (w, cam), hw in ((scenes.mixed_scene(200, 120), (120, 200)), (scenes.teapot_scene(640, 360), (360, 640))):
+        full = cam.render(w)
+        cd = cam.desc()
+        for n_ranks in (1, 2):
+            frame = torch.full(hw + (3,), -7.0, dtype=torch.float64, device=dev)
+            fid = torch.full(hw, -7, dtype=torch.int32, device=dev)
+            ffl = torch.full(hw, 77, dtype=torch.uint8, device=dev)
+            for rep in range(2):  # second pass replays the captured frame
+                for r in range(n_ranks):
+                    opts = rt.RenderOpts(max_depth=5, rank=r, n_ranks=n_ranks, want_counters=0, stream=None)
+                    assert rt.lib.rt_render_frame(w.scene(), C.byref(cd), C.byref(opts), frame.data_ptr(), fid.data_ptr(),
+                                                  ffl.data_ptr(), None) == 0, rt.last_error()
+                torch.cuda.synchronize()
+                assert np.array_equal(frame.cpu().numpy(), full.rgb)
+                assert np.array_equal(fid.cpu().numpy(), full.hit_id)
+                assert np.array_equal(ffl.cpu().numpy(), full.flags)
+                assert not frame[-1].any() and not frame[:, -1].any()
+
+
 def test_instrumented_counters_do_not_change_the_image():
     w, cam = scenes.teapot_scene(160, 90)
     a = cam.render(w)
