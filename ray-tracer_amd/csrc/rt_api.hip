@@ -241,6 +241,18 @@ int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, i
     return launch_trav(s, st, k_secondary<false, COUNT, false>, upper, s->ds, L, ctr, phases);
 }
 
+// k_queue with the tile size that suits the level (n: its ray count, or the capacity that bounds it)
+inline void launch_queue(hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, long long next_cap,
+                         unsigned long long* ctr) {
+    if (n > 1500000) {
+        constexpr long long T = (long long)TILE_ITERS * BLOCK;
+        hipLaunchKernelGGL(k_queue<TILE_ITERS>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+    } else {
+        constexpr long long T = (long long)TILE_ITERS_SMALL * BLOCK;
+        hipLaunchKernelGGL(k_queue<TILE_ITERS_SMALL>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+    }
+}
+
 // Maximum number of recursion levels a frame can be enqueued for without a host round trip per level
 // (one counter block per level).
 constexpr int ASYNC_LEVELS = 34;
@@ -264,7 +276,7 @@ int enqueue_levels_async(rt_scene* s, hipStream_t st, long long n0, int max_dept
         const unsigned long long* n_dev = d == 0 ? nullptr : s->d_counters + size_t(d - 1) * CNT_TOTAL + CNT_NEXT;
         int rc = launch_trace<false>(s, st, L, n, n_dev, remaining, ctr);
         if (rc != RT_OK) return rc;
-        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+        launch_queue(st, L, n, n_dev, next_cap, ctr);
         if (want) {
             rc = launch_secondary<false>(s, st, L, n, want, ctr);
             if (rc != RT_OK) return rc;
@@ -342,7 +354,7 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool co
             }
         }
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_queue, dim3(unsigned((n + TILE - 1) / TILE)), dim3(BLOCK), 0, st, L, n, (const unsigned long long*)nullptr, next_cap, s->d_counters);
+        launch_queue(st, L, n, nullptr, next_cap, s->d_counters);
         tm.end();
         const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
         if (counters && stats) {  // instrumented run: one queue per launch, so that the work counters stay apart

@@ -1240,28 +1240,37 @@ __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n
 // Queue appends without an atomic per wavefront (returning atomics on one word are serialised in L2, 5-10 ns each
 // chip-wide): a workgroup owns a TILE of consecutive rays, counts its appends in a first pass over the stage bits,
 // reserves its slots with ONE atomic per queue, then writes the entries in a second pass with slots known.
+// A tile is ITERS x BLOCK rays: 8192 for large levels (few atomics), 2048 for small ones (a level of 300k rays would
+// otherwise occupy 37 of the 256 compute units and take as long as one of 2M).
 constexpr int TILE_ITERS = 32;
-constexpr int TILE = TILE_ITERS * BLOCK;
+constexpr int TILE_ITERS_SMALL = 8;
 struct TileSlots {
     int off[4][TILE_ITERS][BLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
     long long base[3];                   // shadow queue, container queue, next level
 };
 
+template <int ITERS>
 __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const unsigned long long* n_dev, long long next_cap,
                                                  unsigned long long* counters) {
+    constexpr int TILE = ITERS * BLOCK;
     const long long n = level_count(n_cap, n_dev);
     if ((long long)blockIdx.x * TILE >= n) return;  // whole workgroup beyond the level
     __shared__ TileSlots ts;
     const long long tile0 = (long long)blockIdx.x * TILE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int stage[TILE_ITERS];
+    if (ITERS < TILE_ITERS) {  // the scan below runs over all TILE_ITERS x 4 counts: the unused ones are zero
+        int* flat = &ts.off[0][0][0];
+        for (int q = 0; q < 4; ++q)
+            for (int k = ITERS * (BLOCK / 64) + threadIdx.x; k < TILE_ITERS * (BLOCK / 64); k += BLOCK) flat[q * TILE_ITERS * (BLOCK / 64) + k] = 0;
+    }
+    int stage[ITERS];
 #pragma unroll
-    for (int it = 0; it < TILE_ITERS; ++it) {  // independent coalesced loads, all in flight together
+    for (int it = 0; it < ITERS; ++it) {  // independent coalesced loads, all in flight together
         long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
         stage[it] = i < n ? L.mode[i] : 0;
     }
 #pragma unroll
-    for (int it = 0; it < TILE_ITERS; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         unsigned long long b0 = __ballot(stage[it] & ST_HIT), b1 = __ballot(stage[it] & ST_WALK);
         unsigned long long b2 = __ballot(stage[it] & ST_REFLECT), b3 = __ballot(stage[it] & ST_REFRACT);
         if (lane == 0) {
@@ -1306,7 +1315,7 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < TILE_ITERS; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
         const int st = stage[it];
         unsigned long long b0 = __ballot(st & ST_HIT), b1 = __ballot(st & ST_WALK);
