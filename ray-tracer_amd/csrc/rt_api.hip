@@ -694,6 +694,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     UP(upload(s, prog.chain_pool, &s->ds.chain_pool));
     UP(upload(s, prog.bvh, &s->ds.bvh));
     UP(upload(s, prog.mesh_tris, &s->ds.mesh_tris));
+    UP(upload(s, prog.mesh_dups, &s->ds.mesh_dups));
     UP(upload(s, prog.mesh_box, &s->ds.mesh_box));
 #undef UP
     s->ds.n_lights = d.n_lights;

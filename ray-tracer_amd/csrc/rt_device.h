@@ -60,6 +60,7 @@ struct DScene {
     const int32_t* chain_pool;
     const BvhNode* bvh;
     const MeshTri* mesh_tris;
+    const int32_t* mesh_dups;         // node lists of repeated triangles (MeshTri::smooth bits 1..)
     const double* mesh_box;           // [n_meshes][6] padded f64 box of each mesh (ITEM_MESH.b indexes it)
     int32_t all_cast_shadow;
     int32_t n_lds;                    // BVH nodes [0, n_lds) are staged in LDS by the traversal kernels

@@ -513,8 +513,19 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 pin(tb.p1); pin(tb.e1); pin(tb.e2); pin(tb.node); pin(tb.smooth);
                 const TriHit ha = tri_eval<COUNT>(o, d, ta.p1, ta.e1, ta.e2, true, w);
                 const TriHit hb = tri_eval<COUNT>(o, d, tb.p1, tb.e1, tb.e2, two, w);
-                if (ha.ok) e(ha.t, ta.node * 4, ha.u, ha.v, ta.smooth);
-                if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth);
+                if (ha.ok) e(ha.t, ta.node * 4, ha.u, ha.v, ta.smooth & 1);
+                if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth & 1);
+                // a hit on a repeated triangle counts once per node that carries it (rt_program.cpp: build_mesh)
+                if ((ha.ok && (ta.smooth >> 1)) || (hb.ok && (tb.smooth >> 1))) {
+                    if (ha.ok && (ta.smooth >> 1)) {
+                        const int* __restrict__ dl = S.mesh_dups + (ta.smooth >> 1) - 1;
+                        for (int j = 1, c = dl[0]; j <= c; ++j) e(ha.t, dl[j] * 4, ha.u, ha.v, ta.smooth & 1);
+                    }
+                    if (hb.ok && (tb.smooth >> 1)) {
+                        const int* __restrict__ dl = S.mesh_dups + (tb.smooth >> 1) - 1;
+                        for (int j = 1, c = dl[0]; j <= c; ++j) e(hb.t, dl[j] * 4, hb.u, hb.v, tb.smooth & 1);
+                    }
+                }
             }
         }
         if (sp == 0 || sink.done()) break;

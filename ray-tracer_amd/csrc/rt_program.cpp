@@ -53,7 +53,8 @@ struct Compiler {
 
     // ---- BVH -------------------------------------------------------------------------------------------
     struct TriRef {
-        int32_t node;
+        int32_t node;   // lowest node among the identical triangles this entry stands for
+        int32_t dups;   // 0, or 1 + offset into p.mesh_dups of [count, node, node, ...]: the other nodes, ascending
         double lo[3], hi[3], c[3];
     };
     struct Box {
@@ -92,7 +93,7 @@ struct Compiler {
                 mt.e2[k] = d.tri_e2[3 * t + k];
             }
             mt.node = node;
-            mt.smooth = d.node_kind[node] == RT_SMOOTH_TRIANGLE ? 1 : 0;
+            mt.smooth = (d.node_kind[node] == RT_SMOOTH_TRIANGLE ? 1 : 0) | (refs[i].dups << 1);
             p.mesh_tris.push_back(mt);
         }
         return ~((first << 2) | int32_t(hi - lo - 1));
@@ -245,12 +246,46 @@ struct Compiler {
         return me;
     }
 
-    int32_t build_mesh(const std::vector<int32_t>& tri_nodes) {
+    int32_t build_mesh(const std::vector<int32_t>& all_tri_nodes) {
+        // Triangles with bit-identical p1, e1, e2 and kind give bit-identical test results for every ray: they are
+        // tested once and the hit is emitted for each of their nodes (the reference's parser repeats triangles by the
+        // hundred on polygon faces, F3: teapot-low.obj is 15,136 triangles but 151 distinct ones).
+        std::vector<int32_t> tri_nodes;
+        std::vector<int32_t> dups_of;
+        {
+            struct Key {
+                double v[9];
+                int32_t kind;
+                bool operator<(const Key& o) const {
+                    int c = std::memcmp(v, o.v, sizeof v);
+                    return c != 0 ? c < 0 : kind < o.kind;
+                }
+            };
+            std::map<Key, size_t> seen;
+            std::vector<std::vector<int32_t>> extra;
+            for (int32_t node : all_tri_nodes) {
+                int32_t t = d.node_param[node];
+                Key k;
+                for (int j = 0; j < 3; ++j) { k.v[j] = d.tri_p1[3 * t + j]; k.v[3 + j] = d.tri_e1[3 * t + j]; k.v[6 + j] = d.tri_e2[3 * t + j]; }
+                k.kind = d.node_kind[node];
+                auto ins = seen.emplace(k, tri_nodes.size());
+                if (ins.second) { tri_nodes.push_back(node); extra.emplace_back(); }
+                else extra[ins.first->second].push_back(node);  // all_tri_nodes ascends, so does every list
+            }
+            dups_of.assign(tri_nodes.size(), 0);
+            for (size_t i = 0; i < tri_nodes.size(); ++i) {
+                if (extra[i].empty()) continue;
+                dups_of[i] = int32_t(p.mesh_dups.size()) + 1;
+                p.mesh_dups.push_back(int32_t(extra[i].size()));
+                p.mesh_dups.insert(p.mesh_dups.end(), extra[i].begin(), extra[i].end());
+            }
+        }
         std::vector<TriRef> refs(tri_nodes.size());
         double maxabs = 0.;
         for (size_t i = 0; i < tri_nodes.size(); ++i) {
             TriRef& r = refs[i];
             r.node = tri_nodes[i];
+            r.dups = dups_of[i];
             int32_t t = d.node_param[r.node];
             for (int k = 0; k < 3; ++k) {
                 double a = d.tri_p1[3 * t + k], b = a + d.tri_e1[3 * t + k], c = a + d.tri_e2[3 * t + k];

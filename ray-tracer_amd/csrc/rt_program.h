@@ -58,7 +58,8 @@ static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 struct MeshTri {
     double p1[3], e1[3], e2[3];  // src/triangle.rs:17-21
     int32_t node;                // leaf node index (emission order + shading look-ups)
-    int32_t smooth;              // 1 = SmoothTriangle (keeps u,v)
+    int32_t smooth;              // bit 0: SmoothTriangle (keeps u,v);  bits 1..: 0, or 1 + offset into mesh_dups of
+                                 // [count, node, ...] — further nodes with the bit-identical triangle (tested once)
 };
 static_assert(sizeof(MeshTri) == 80, "MeshTri must be 80 bytes");
 
@@ -69,6 +70,7 @@ struct Program {
                                        // (registry chain of src/shape.rs:394-420, identities kept)
     std::vector<BvhNode> bvh;
     std::vector<MeshTri> mesh_tris;
+    std::vector<int32_t> mesh_dups;    // node lists of repeated triangles (MeshTri::smooth)
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
     bool has_smooth = false;

@@ -4,7 +4,7 @@ profiles/pmc_traffic.json: HBM-side bytes per launch of each kernel of the rende
 Units / corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE tallies
 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE is taken as is.  The guide calibrated this for
 16-byte-per-lane streams; our level columns are 8-byte-per-lane SoA streams, so two kernels with exactly known
-traffic (k_raygen: stores only, k_output: loads + stores) are reported as a calibration check next to the result.
+traffic (k_raygen: stores only) is reported as a calibration check next to the result.
 
 usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections
@@ -44,12 +44,14 @@ def main():
     res["_method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --steps 2 --warmup 1 "
                       "--no-cpu-baseline`; bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction) + WRITE_SIZE KiB x 1024; "
                       "averaged over every launch of the kernel in the run (all recursion levels)")
-    if "k_assemble" in res:  # known traffic: reads 24 B and writes 24 B per rendered pixel of the 1919 x 1079 domain
-        exp = 1919 * 1079 * 24
-        res["_calibration"] = {"k_assemble_expected_read_bytes": exp, "k_assemble_measured_read_bytes": res["k_assemble"]["hbm_read_bytes_per_launch"],
-                               "k_assemble_expected_write_bytes": exp, "k_assemble_measured_write_bytes": res["k_assemble"]["hbm_write_bytes_per_launch"],
-                               "note": "8-byte-per-lane SoA streams of the default 1920x1080 bench: WRITE_SIZE and FETCH_SIZE x 2 both land within "
-                                       "0.2 % of the known byte counts, so the guide's gfx950 correction holds for this access pattern"}
+    if "k_raygen" in res:  # known traffic: k_raygen only stores, 48 B per ray of the 1919 x 1079 domain (two chains: half each)
+        per_launch = res["k_raygen"]["hbm_write_bytes_per_launch"]
+        exp_full = 1919 * 1079 * 48
+        res["_calibration"] = {"k_raygen_expected_write_bytes_full_frame": exp_full, "k_raygen_measured_write_bytes_per_launch": per_launch,
+                               "launches_per_frame_when_chained": 2,
+                               "note": "8-byte-per-lane SoA streams of the default 1920x1080 bench; a chained frame launches k_raygen once per "
+                                       "sub-shard (half the rays each), an unchained one once; WRITE_SIZE lands on the known byte count, and "
+                                       "FETCH_SIZE x 2 was checked the same way on k_assemble in the r01d set"}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         if k.startswith("k_"):

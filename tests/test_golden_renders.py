@@ -22,6 +22,15 @@ BUILDERS = {
 NAMES = sorted(BUILDERS)
 
 
+def _same_ids(got, want):
+    """Object ids come from a process-wide counter (src/lib.rs:46), so a scene built after other scenes carries the
+    fixture's ids plus a constant: hits are compared after removing that constant (0 = miss stays 0)."""
+    if not (got > 0).any() or not (want > 0).any():
+        return np.array_equal(got, want)
+    shift = int(got[got > 0].min()) - int(want[want > 0].min())
+    return np.array_equal(np.where(got > 0, got - shift, 0), want)
+
+
 def _load(name):
     z = np.load(os.path.join(GOLDEN, f"render_{name}.npz"), allow_pickle=False)
     w, h, depth = (int(x) for x in z["size"])
@@ -39,7 +48,7 @@ def test_oracle_reproduces_the_golden_render(name):
     world, cam = BUILDERS[name](w, h)
     img = ob.render(world, cam, depth)
     assert np.array_equal(img.rgb, z["rgb"], equal_nan=True)
-    assert np.array_equal(img.hit_id, z["hit_id"]) and np.array_equal(img.flags, z["flags"])
+    assert _same_ids(img.hit_id, z["hit_id"]) and np.array_equal(img.flags, z["flags"])
     st = img.stats
     assert [st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes] == z["counts"].tolist()
 
@@ -51,7 +60,7 @@ def test_device_matches_the_golden_render(name):
     world, cam = BUILDERS[name](w, h)
     for want_stats in (True, False):
         img = cam.render(world, depth, want_stats=want_stats)
-        assert np.array_equal(img.hit_id, z["hit_id"]) and np.array_equal(img.flags, z["flags"])
+        assert _same_ids(img.hit_id, z["hit_id"]) and np.array_equal(img.flags, z["flags"])
         err = np.abs(img.rgb - z["rgb"])
         err[np.isnan(img.rgb) & np.isnan(z["rgb"])] = 0.
         assert float(err.max()) < 1e-9

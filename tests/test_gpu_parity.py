@@ -193,6 +193,41 @@ def test_intersection_lists_match_on_the_teapot():
     assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
 
 
+def _repeated_triangle_world(material):
+    """Polygon faces through the reference parser's fan bug (F3): every face repeats one triangle several times.  The
+    library tests bit-identical triangles once and emits the hit for each node that carries it."""
+    obj = "\n".join(["v -2 0 0", "v 2 0 0", "v 2 3 0", "v 0 4 0", "v -2 3 0", "v -1 0 1", "v 1 0 1", "v 1 3 1.5", "v -1 3 1.5",
+                     "v 0 1 -1", "v 3 1 -1", "v 0 4 -1",
+                     "f 1 2 3 4 5", "f 6 7 8 9", "f 1 2 3 4 5", "f 10 11 12", "f 9 8 7 6 1 2"] + ["f 10 11 12"] * 3) + "\n"
+    g, _ = rt.obj_to_group(obj)
+    g.set_material(material)
+    w = World()
+    w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
+    w.objects += [Shape.plane().set_transform(translate(0., -0.5, 0.)), g]
+    return w
+
+
+def test_repeated_triangles_are_tested_once_and_listed_every_time():
+    w = _repeated_triangle_world(Material(color=(0.8, 0.3, 0.2), reflective=0.2))
+    assert w.flatten().contents.n_triangles >= 12
+    o, d = _random_rays(3000, 5, center=(0., 2., 0.), radius=8.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert gc.max() >= 6  # one geometric hit, listed once per repeat
+    for mat in (Material(color=(0.8, 0.3, 0.2), reflective=0.2),
+                Material(color=(0.9, 1., 0.9), diffuse=0.3, reflective=0.5, transparency=0.7, refractive_index=1.4)):
+        w = _repeated_triangle_world(mat)
+        cam = Camera(96, 64, PI / 3.)
+        cam.transform = view_transform((1.5, 3., -9.), (0., 1.8, 0.), (0., 1., 0.))
+        assert_image_parity(w, cam)
+        g_rgb, g_id, g_fl = w.color_at_batch(o[:800], d[:800], 5)
+        o_rgb, o_id, o_fl = ob.color_at_batch(w, o[:800], d[:800], 5)
+        assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl)
+        assert float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+        assert np.array_equal(w.is_shadowed_batch(o[:800]), ob.is_shadowed_batch(w, o[:800]))
+
+
 @pytest.mark.parametrize("builder", [scenes.mixed_scene, scenes.teapot_scene])
 def test_color_at_and_shadows_for_random_rays(builder):
     w, _ = builder(32, 32)
