@@ -56,6 +56,7 @@ struct rt_scene {
     DScene ds{};
     std::vector<void*> allocs;
     bool has_csg = false, has_smooth = false, any_transparent = false;
+    int scene_class = 0;  // SC_CSG | SC_CULL: which traversal kernel variants this scene runs
     int n_lights = 0;
     std::vector<LevelStore> levels;
     unsigned long long* d_counters = nullptr;
@@ -219,26 +220,36 @@ int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... 
 }
 inline long long chunks_for(long long n) { return (n + 63) / 64; }  // small launches spread over all CUs, a few chunks each
 
+// Kernel variants are compiled per scene class (rt_kernels.hip.h: SC_CSG | SC_CULL).
+#define RT_BY_SCENE_CLASS(sc, CALL) \
+    switch (sc) {                   \
+        case 0: CALL(0); break;     \
+        case 1: CALL(1); break;     \
+        case 2: CALL(2); break;     \
+        default: CALL(3); break;    \
+    }
 template <bool COUNT>
 int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, int remaining,
                  unsigned long long* ctr) {
-    if (s->has_csg) {
-        if (s->has_smooth) return launch_trav(s, st, k_trace<true, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
-        return launch_trav(s, st, k_trace<true, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
-    }
-    if (s->has_smooth) return launch_trav(s, st, k_trace<false, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
-    return launch_trav(s, st, k_trace<false, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr);
+    int rc = RT_OK;
+#define RT_CALL(SC)                                                                                                          \
+    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr)  \
+                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr)
+    RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
+#undef RT_CALL
+    return rc;
 }
 template <bool COUNT>
 int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases, unsigned long long* ctr) {
     // upper bound of the chunk count: the queue lengths live on the device
     const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1)) + chunks_for(n);
-    if (s->has_csg) {
-        if (s->any_transparent) return launch_trav(s, st, k_secondary<true, COUNT, true>, upper, s->ds, L, ctr, phases);
-        return launch_trav(s, st, k_secondary<true, COUNT, false>, upper, s->ds, L, ctr, phases);
-    }
-    if (s->any_transparent) return launch_trav(s, st, k_secondary<false, COUNT, true>, upper, s->ds, L, ctr, phases);
-    return launch_trav(s, st, k_secondary<false, COUNT, false>, upper, s->ds, L, ctr, phases);
+    int rc = RT_OK;
+#define RT_CALL(SC)                                                                                              \
+    rc = s->any_transparent ? launch_trav(s, st, k_secondary<SC, COUNT, true>, upper, s->ds, L, ctr, phases)   \
+                            : launch_trav(s, st, k_secondary<SC, COUNT, false>, upper, s->ds, L, ctr, phases)
+    RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
+#undef RT_CALL
+    return rc;
 }
 
 // k_queue with the tile size that suits the level (n: its ray count, or the capacity that bounds it)
@@ -722,6 +733,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         if (!(std::isfinite(ri) && ri > 0.)) s->ds.walk_at_zero = 1;
     }
     s->has_csg = prog.has_csg;
+    s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0);
     s->has_smooth = prog.has_smooth;
     s->n_lights = d.n_lights;
     for (int m = 0; m < d.n_materials; ++m) {  // does any material ever need the n1/n2 walk?
@@ -964,11 +976,11 @@ int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const
     HIP_TRY(hipMemsetAsync(s->misc_b.p, 0, lb * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(s->misc_c.p, 0, lb * sizeof(int32_t), st));
     if (s->has_csg)
-        rc = launch_trav(s, st, k_list<true>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+        rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
                          static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
                          static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
     else
-        rc = launch_trav(s, st, k_list<false>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
+        rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
                          static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
                          static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
     if (rc != RT_OK) return rc;
@@ -995,10 +1007,10 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
     if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->misc_a, ob)) != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
     if (s->has_csg)
-        rc = launch_trav(s, st, k_shadow_points<true>, chunks_for(n_points), s->ds, (long long)n_points,
+        rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL>, chunks_for(n_points), s->ds, (long long)n_points,
                          static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
     else
-        rc = launch_trav(s, st, k_shadow_points<false>, chunks_for(n_points), s->ds, (long long)n_points,
+        rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n_points), s->ds, (long long)n_points,
                          static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
     if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());

@@ -566,8 +566,12 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // therefore fetched once per wavefront with scalar loads, and the kind switch is a scalar branch.  When every lane
 // sleeps, the walk jumps to the nearest wake-up item.  `alive` = this lane has a ray at all; callers run traverse
 // with the whole wavefront executing.
-template <bool HAS_CSG, bool COUNT, class Sink>
+// SC = scene class: bit 0 the scene has CSG nodes, bit 1 its program has ITEM_CULL ranges (code for either is only
+// compiled into the kernels of scenes that need it).
+constexpr int SC_CSG = 1, SC_CULL = 2;
+template <int SC, bool COUNT, class Sink>
 __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive) {
+    constexpr bool HAS_CSG = (SC & SC_CSG) != 0, HAS_CULL = (SC & SC_CULL) != 0;
     CsgScratch* cs = nullptr;
     CsgScratch cs_storage;
     if (HAS_CSG) {
@@ -648,6 +652,19 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                     cs->n = 0;
                 }
             }
+            continue;
+        }
+        if (HAS_CULL && it.type == ITEM_CULL) {  // acceleration: world-space bounds of the top-level objects up to it.skip
+            if (on) {
+                const RT_CONSTANT double* __restrict__ cb = reinterpret_cast<const RT_CONSTANT double*>(items + (i - 1)) + 2;
+                // 1/d is recomputed per range rather than kept: worlds without ranges (the headline scene) must not pay
+                // registers for it, and a range that culls saves far more than three reciprocals
+                const V3 inv_world = mk(slab_rcp(rd.x), slab_rcp(rd.y), slab_rcp(rd.z));
+                double tnear;
+                bump<COUNT>(w.box);
+                if (!bvh_box(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], ro, inv_world, sink.lo(), sink.hi(), tnear)) until = it.skip;
+            }
+            if (__ballot(i >= until) == 0) i = wave_min_i32(until);  // nobody needs the range: jump, uniformly
             continue;
         }
         // Ray::transform per level, outermost first (src/shape.rs:75-76, src/ray.rs:25-30)
@@ -1059,7 +1076,7 @@ __device__ __forceinline__ V3 lighting(const DScene& S, const double* __restrict
 }
 
 // World::is_shadowed for one light (src/world.rs:92-107): NEAREST hit only, then `t < distance && casts_shadow` (F8)
-template <bool HAS_CSG, bool COUNT>
+template <int SC, bool COUNT>
 __device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V3 point, int light, Work& w, unsigned& flags,
                                             bool alive) {
     const double* __restrict__ l = S.light + (size_t)light * 6;
@@ -1072,21 +1089,21 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V
     // F8: the answer is `nearest.t < distance && nearest.casts_shadow`.  When EVERY leaf of the scene casts shadows that
     // is "some hit has 0 < t < distance", and the first such hit ends the search; otherwise the nearest must be found.
     if (S.all_cast_shadow) sink.stop_below = distance;
-    traverse<HAS_CSG, COUNT>(S, M, point, direction, sink, w, alive);
+    traverse<SC, COUNT>(S, M, point, direction, sink, w, alive);
     flags |= sink.flags;
     if (sink.best_key < 0) return false;
     return sink.best_t < distance && S.node_casts_shadow[sink.best_key >> 2] != 0;
 }
 
 // The n1/n2 walk of prepare_computations (src/intersection.rs:54-80) over the sorted list up to the hit.
-template <bool HAS_CSG, bool COUNT>
+template <int SC, bool COUNT>
 __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M, V3 o, V3 d, double hit_t, int hit_node, Work& w,
                                                double& n1_out, double& n2_out, unsigned& flags, bool alive) {
     double lt[LIST_CAP];
     int lk[LIST_CAP];
     ListSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
-    traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
+    traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
     flags |= sink.flags;
     int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     sort_list(lt, lk, n);
@@ -1173,7 +1190,7 @@ __device__ __forceinline__ long long level_count(long long n, const unsigned lon
 }
 
 // `remaining` is the value color_at was called with at this level.
-template <bool HAS_CSG, bool NEED_FIRST, bool COUNT>
+template <int SC, bool NEED_FIRST, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
                                                   unsigned long long* counters) {
     const long long n = level_count(n_cap, n_dev);
@@ -1200,7 +1217,7 @@ __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n
         if (!alive) o = mk(0., 0., 0.);
         ClosestSink<NEED_FIRST> sink;
         sink.init(INFINITY);
-        traverse<HAS_CSG, COUNT>(S, M, o, d, sink, w, alive);
+        traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
         const long long c_next = feed.next();
         V3 o_next, d_next;
         fetch(c_next, o_next, d_next);
@@ -1349,7 +1366,7 @@ __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(
 // One launch serves both queues of a level (`phases` bit 0: shadow queue, bit 1: container queue; the instrumented
 // run launches them one at a time to keep their work counters apart).  The container chunks — few, and each one a
 // long latency-bound walk — go first, so that they overlap the bulk of the shadow chunks instead of forming a tail.
-template <bool HAS_CSG, bool COUNT, bool WALK>
+template <int SC, bool COUNT, bool WALK>
 __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigned long long* counters, int phases) {
     const long long n_shadow = (phases & 1) ? (long long)counters[CNT_SHADOW_Q] * S.n_lights : 0;
     const long long n_walk = (WALK && (phases & 2)) ? (long long)counters[CNT_CONTAINER_Q] : 0;
@@ -1376,7 +1393,7 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
             unsigned flags = 0;
             double n1, n2;
             bool tir = false;
-            container_walk<HAS_CSG, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
+            container_walk<SC, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
             if (alive) {
                 L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
                 L.hv[i] = n2;
@@ -1407,7 +1424,7 @@ __global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigne
             over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
         }
         unsigned flags = 0;
-        bool sh = is_shadowed<HAS_CSG, COUNT>(S, M, over_point, light, w, flags, alive);
+        bool sh = is_shadowed<SC, COUNT>(S, M, over_point, light, w, flags, alive);
         if (alive) {
             L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
             if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
@@ -1539,7 +1556,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_
 }
 
 // Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
-template <bool HAS_CSG>
+template <int SC>
 __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
                                                  const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
                                                  int32_t* id_out) {
@@ -1558,7 +1575,7 @@ __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const do
             o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
             d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
         }
-        traverse<HAS_CSG, false>(S, M, o, d, sink, w, alive);
+        traverse<SC, false>(S, M, o, d, sink, w, alive);
         if (!alive) continue;
         int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
         sort_list(lt, lk, m);
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const do
 }
 
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
-template <bool HAS_CSG>
+template <int SC>
 __global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
     Feed feed;
     const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
@@ -1582,7 +1599,7 @@ __global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n,
         unsigned flags = 0;
         V3 p = alive ? mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]) : mk(0., 0., 0.);
         for (int l = 0; l < S.n_lights; ++l) {
-            bool sh = is_shadowed<HAS_CSG, false>(S, M, p, l, w, flags, alive);
+            bool sh = is_shadowed<SC, false>(S, M, p, l, w, flags, alive);
             if (alive) out[i * S.n_lights + l] = sh ? 1 : 0;
         }
     }

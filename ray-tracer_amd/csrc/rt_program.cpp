@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -331,6 +332,176 @@ struct Compiler {
         for (size_t it : mesh_items) p.items[it].a = where[size_t(p.items[it].a)];
     }
 
+    // ---- world-space bounds of top-level objects (ITEM_CULL) --------------------------------------------------
+    struct WBox {
+        double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+        bool bounded = true;  // false: unbounded or not computable — never culled
+        void add(const WBox& o) {
+            bounded = bounded && o.bounded;
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); }
+        }
+    };
+    std::map<int32_t, std::vector<double>> forward_cache;  // xform index -> 12 doubles of the forward matrix, empty: singular
+    const std::vector<double>& forward_of(int32_t x) {
+        auto it = forward_cache.find(x);
+        if (it != forward_cache.end()) return it->second;
+        const double* m = d.xform_inverse + size_t(x) * 16;  // affine: rows 0..2 are [A | t], forward = [A^-1 | -A^-1 t]
+        const double a = m[0], b = m[1], c = m[2], e = m[4], f = m[5], g = m[6], h = m[8], i = m[9], j = m[10];
+        const double det = a * (f * j - g * i) - b * (e * j - g * h) + c * (e * i - f * h);
+        std::vector<double> out;
+        if (std::isfinite(det) && std::fabs(det) > 0.) {
+            const double inv[9] = {(f * j - g * i) / det, (c * i - b * j) / det, (b * g - c * f) / det,
+                                   (g * h - e * j) / det, (a * j - c * h) / det, (c * e - a * g) / det,
+                                   (e * i - f * h) / det, (b * h - a * i) / det, (a * f - b * e) / det};
+            out.resize(12);
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 0; k < 3; ++k) out[size_t(4 * r + k)] = inv[3 * r + k];
+                out[size_t(4 * r + 3)] = -(inv[3 * r] * m[3] + inv[3 * r + 1] * m[7] + inv[3 * r + 2] * m[11]);
+            }
+        }
+        return forward_cache.emplace(x, out).first->second;
+    }
+    // object-space box -> world, through the non-identity transforms `chain` (outermost first)
+    WBox to_world(const double* lo, const double* hi, const std::vector<int32_t>& chain) {
+        WBox w;
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { w.bounded = false; return w; }
+        double pts[8][3];
+        for (int c = 0; c < 8; ++c)
+            for (int k = 0; k < 3; ++k) pts[c][k] = ((c >> k) & 1) ? hi[k] : lo[k];
+        for (size_t lv = chain.size(); lv-- > 0;) {  // innermost first
+            const std::vector<double>& fm = forward_of(chain[lv]);
+            if (fm.empty()) { w.bounded = false; return w; }
+            for (auto& p : pts) {
+                const double q[3] = {p[0], p[1], p[2]};
+                for (int r = 0; r < 3; ++r) p[r] = fm[size_t(4 * r)] * q[0] + fm[size_t(4 * r + 1)] * q[1] + fm[size_t(4 * r + 2)] * q[2] + fm[size_t(4 * r + 3)];
+            }
+        }
+        for (const auto& p : pts)
+            for (int k = 0; k < 3; ++k) {
+                if (!std::isfinite(p[k])) { w.bounded = false; return w; }
+                w.lo[k] = std::min(w.lo[k], p[k]);
+                w.hi[k] = std::max(w.hi[k], p[k]);
+            }
+        return w;
+    }
+    WBox world_box(int32_t node, std::vector<int32_t> chain) {
+        int32_t x = d.node_xform[node];
+        if (x != 0) chain.push_back(x);
+        const int32_t kind = d.node_kind[node];
+        const double unit_lo[3] = {-1., -1., -1.}, unit_hi[3] = {1., 1., 1.};
+        switch (kind) {
+            case RT_SPHERE: case RT_CUBE: return to_world(unit_lo, unit_hi, chain);
+            case RT_PLANE: { WBox w; w.bounded = false; return w; }
+            case RT_CONE: {
+                // never bounded: a ray parallel to the cone's side gets its single hit WITHOUT the minimum < y < maximum
+                // test (src/cone.rs:61-64), i.e. anywhere on the infinite double cone
+                WBox w;
+                w.bounded = false;
+                return w;
+            }
+            case RT_CYLINDER: {
+                const int32_t q = d.node_param[node];
+                const double mn = d.conic_minimum[q], mx = d.conic_maximum[q];
+                // the caps accept x^2 + z^2 < 1 or within EPSILON of 1 (src/cylinder.rs:96-101): radius^2 up to 1 + 1e-5
+                const double r = std::sqrt(1. + 2e-5);
+                const double lo[3] = {-r, std::min(mn, mx), -r}, hi[3] = {r, std::max(mn, mx), r};
+                return to_world(lo, hi, chain);
+            }
+            case RT_TRIANGLE: case RT_SMOOTH_TRIANGLE: {
+                const int32_t t = d.node_param[node];
+                double lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    const double a = d.tri_p1[3 * t + k], b = a + d.tri_e1[3 * t + k], c = a + d.tri_e2[3 * t + k];
+                    lo[k] = std::min(a, std::min(b, c));
+                    hi[k] = std::max(a, std::max(b, c));
+                }
+                return to_world(lo, hi, chain);
+            }
+            case RT_GROUP: {
+                // children without a transform of their own share this chain: unite them in object space first
+                WBox w;
+                double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+                bool any_plain = false;
+                for (int32_t c = node + 1; c < d.node_subtree_end[node]; c = d.node_subtree_end[c]) {
+                    if (is_tri_kind(d.node_kind[c]) && d.node_xform[c] == 0) {
+                        const int32_t t = d.node_param[c];
+                        for (int k = 0; k < 3; ++k) {
+                            const double a = d.tri_p1[3 * t + k], b = a + d.tri_e1[3 * t + k], e = a + d.tri_e2[3 * t + k];
+                            lo[k] = std::min(lo[k], std::min(a, std::min(b, e)));
+                            hi[k] = std::max(hi[k], std::max(a, std::max(b, e)));
+                        }
+                        any_plain = true;
+                    } else {
+                        w.add(world_box(c, chain));
+                    }
+                }
+                if (any_plain) w.add(to_world(lo, hi, chain));
+                return w;
+            }
+            default: {  // CSG: whatever survives the filter lies on an operand
+                const int32_t left = node + 1, right = d.node_subtree_end[left];
+                WBox w = world_box(left, chain);
+                w.add(world_box(right, chain));
+                return w;
+            }
+        }
+    }
+    // Emits the bounded top-level objects `roots[lo, hi)` as a tree of ITEM_CULL ranges (median split of the box
+    // centres on their widest axis).  Only worth it in a world of many objects: a range costs every ray one more item
+    // (a dependent scalar fetch), and with the headline scene's three bounded objects that lost 4 % of the frame, while
+    // the 32-object grid of C5 renders 1.85x faster with it and the 8-object C4 1.17x.
+    static constexpr size_t CULL_MIN_OBJECTS = 6;
+    void emit_culled(std::vector<std::pair<int32_t, WBox>>& roots, size_t lo, size_t hi) {
+        if (hi - lo == 0) return;
+        const char* env = std::getenv("RT_AMD_CULL");  // 0: never (A/B tests of the acceleration)
+        if (roots.size() < CULL_MIN_OBJECTS || (env && env[0] == '0')) {
+            for (size_t i = lo; i < hi; ++i) emit(roots[i].first, {});
+            return;
+        }
+        WBox all;
+        for (size_t i = lo; i < hi; ++i) all.add(roots[i].second);
+        int32_t cull = -1;
+        {
+            Item it{};
+            it.type = ITEM_CULL;
+            double* b = cull_box(it);
+            for (int k = 0; k < 3; ++k) {
+                // hits are computed in object space from the inverse matrices: the bounds are padded far beyond that
+                // arithmetic's error (as the BVH boxes are)
+                const double pad = 1e-7 * std::max(std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])), all.hi[k] - all.lo[k]) + 1e-300;
+                b[k] = all.lo[k] - pad;
+                b[3 + k] = all.hi[k] + pad;
+            }
+            cull = int32_t(p.items.size());
+            p.items.push_back(it);
+            p.has_cull = true;
+        }
+        if (hi - lo == 1) {
+            emit(roots[lo].first, {});
+        } else {
+            int axis = 0;
+            double ext = -1.;
+            for (int k = 0; k < 3; ++k) {
+                double cl = INF, ch = -INF;
+                for (size_t i = lo; i < hi; ++i) {
+                    const double c = 0.5 * roots[i].second.lo[k] + 0.5 * roots[i].second.hi[k];
+                    cl = std::min(cl, c);
+                    ch = std::max(ch, c);
+                }
+                if (ch - cl > ext) { ext = ch - cl; axis = k; }
+            }
+            const size_t mid = lo + (hi - lo) / 2;
+            std::nth_element(roots.begin() + long(lo), roots.begin() + long(mid), roots.begin() + long(hi),
+                             [&](const std::pair<int32_t, WBox>& a, const std::pair<int32_t, WBox>& b) {
+                                 return a.second.lo[axis] + a.second.hi[axis] < b.second.lo[axis] + b.second.hi[axis];
+                             });
+            emit_culled(roots, lo, mid);
+            emit_culled(roots, mid, hi);
+        }
+        if (cull >= 0) p.items[size_t(cull)].skip = int32_t(p.items.size());
+    }
+
     // ---- traversal program -----------------------------------------------------------------------------
     void set_chain(Item& it, const std::vector<int32_t>& chain) {
         it.chain = chain_offset(chain);
@@ -533,9 +704,18 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err) {
         }
         return false;
     };
+    // Top-level objects with bounded extent additionally go under ITEM_CULL ranges (world-space boxes: a ray that
+    // misses a box, or meets it beyond what its sink still accepts, skips everything under it); the unbounded ones
+    // (planes, open cylinders and cones ...) come first, so that their hits already shorten that range.
+    std::vector<std::pair<int32_t, Compiler::WBox>> bounded;
     for (int pass = 0; pass < 2; ++pass)
-        for (int32_t n = 0; n < d.n_nodes; n = d.node_subtree_end[n])
-            if (has_mesh(n) == (pass == 1)) c.emit(n, {});
+        for (int32_t n = 0; n < d.n_nodes; n = d.node_subtree_end[n]) {
+            if (has_mesh(n) != (pass == 1)) continue;
+            Compiler::WBox wb = c.world_box(n, {});
+            if (wb.bounded && wb.lo[0] <= wb.hi[0]) bounded.emplace_back(n, wb);
+            else c.emit(n, {});
+        }
+    c.emit_culled(bounded, 0, bounded.size());
     for (int32_t n = 0; n < d.n_nodes; ++n) {
         int32_t k = d.node_kind[n];
         if (k <= RT_SMOOTH_TRIANGLE) {

@@ -19,7 +19,10 @@ enum ItemType : int32_t {
     ITEM_GATE = 1,       // reference Group gate: node = group node, a = group box index, skip = item after the subtree
     ITEM_MESH = 2,       // BVH over the triangle children of one group: a = BVH root node index
     ITEM_CSG_BEGIN = 3,  // open a CSG scratch segment: node = csg node
-    ITEM_CSG_END = 4     // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op
+    ITEM_CSG_END = 4,    // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op
+    ITEM_CULL = 5        // acceleration only: padded WORLD-space bounds of everything up to item `skip` (a set of top-level
+                         // objects); a ray that misses them, or meets them beyond what its sink still accepts, skips there.
+                         // The six bounds overlay bytes 16..63 of the record (cull_box()).
 };
 
 // One 64-byte record per item: everything the traversal needs for the item arrives with ONE scalar load (the
@@ -41,6 +44,7 @@ struct Item {
     double p0, p1;      // LEAF cylinder / cone: minimum, maximum
 };
 static_assert(sizeof(Item) == 64, "Item must be 64 bytes");
+inline double* cull_box(Item& it) { return reinterpret_cast<double*>(reinterpret_cast<char*>(&it) + 16); }  // lo xyz, hi xyz
 
 // BVH4: the four children's boxes are stored in the parent (one 128-byte fetch decides all four), as f32 rounded
 // OUTWARD from the padded f64 boxes — the device converts back to f64 (exact) and tests in f64, so a stored box
@@ -73,6 +77,7 @@ struct Program {
     std::vector<int32_t> mesh_dups;    // node lists of repeated triangles (MeshTri::smooth)
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
+    bool has_cull = false;             // the program has ITEM_CULL ranges
     bool has_smooth = false;
     bool all_cast_shadow = true;
     int32_t max_chain = 0;

@@ -375,6 +375,31 @@ def test_render_frame_writes_the_canvas_in_device_memory():
                 assert not frame[-1].any() and not frame[:, -1].any()
 
 
+def test_world_space_cull_ranges_change_nothing(monkeypatch):
+    """ITEM_CULL (world-space bounds over sets of top-level objects, worlds of six or more bounded objects) is pure
+    acceleration: renders with and without it are bit-identical, at sizes where grazing hits on cylinder caps (accepted
+    up to EPSILON outside the unit radius) and near box faces occur, and both match the oracle at a small size."""
+    for builder, size, depth in ((scenes.mixed_scene, (1280, 720), 5), (lambda w, h: scenes.instanced_grid(w, h, grid=3), (960, 540), 6),
+                                 (scenes.cover_like_scene, (400, 400), 5)):
+        monkeypatch.setenv("RT_AMD_CULL", "0")
+        w0, cam0 = builder(*size)
+        plain = cam0.render(w0, depth)
+        monkeypatch.delenv("RT_AMD_CULL")
+        w1, cam1 = builder(*size)
+        culled = cam1.render(w1, depth)
+        shift = int(culled.hit_id[culled.hit_id > 0].min()) - int(plain.hit_id[plain.hit_id > 0].min())  # ids: process-wide counter
+        assert np.array_equal(np.where(culled.hit_id > 0, culled.hit_id - shift, 0), plain.hit_id)
+        assert np.array_equal(culled.rgb, plain.rgb, equal_nan=True) and np.array_equal(culled.flags, plain.flags)
+        assert culled.stats.total_rays == plain.stats.total_rays
+    w, cam = scenes.instanced_grid(96, 54, grid=3)
+    assert_image_parity(w, cam, 6)
+    o, d = _random_rays(2000, 9, center=(0., 1.5, 8.), radius=14.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
+
+
 def test_instrumented_counters_do_not_change_the_image():
     w, cam = scenes.teapot_scene(160, 90)
     a = cam.render(w)
