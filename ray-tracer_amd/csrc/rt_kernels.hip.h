@@ -133,6 +133,28 @@ struct ListSink {
 
 __device__ __forceinline__ bool key_less(double ta, int ka, double tb, int kb) { return ta < tb || (ta == tb && ka < kb); }
 
+// A list of at most SHORT_LIST entries held in REGISTERS (every index is a compile-time constant after unrolling), for
+// the n1/n2 walk of the common short lists: see container_walk.
+constexpr int SHORT_LIST = 8;
+struct ShortList {
+    double t[SHORT_LIST];
+    int key[SHORT_LIST];
+    __device__ __forceinline__ void exchange(int a, int b) {  // compile-time a < b: order the pair by (t, key)
+        if (key_less(t[b], key[b], t[a], key[a])) {
+            const double x = t[a]; t[a] = t[b]; t[b] = x;
+            const int y = key[a]; key[a] = key[b]; key[b] = y;
+        }
+    }
+    __device__ __forceinline__ void sort() {  // 19-comparator network for eight inputs; unused slots are (+inf, INT_MAX)
+        exchange(0, 1); exchange(2, 3); exchange(4, 5); exchange(6, 7);
+        exchange(0, 2); exchange(1, 3); exchange(4, 6); exchange(5, 7);
+        exchange(1, 2); exchange(5, 6);
+        exchange(0, 4); exchange(1, 5); exchange(2, 6); exchange(3, 7);
+        exchange(2, 4); exchange(3, 5);
+        exchange(1, 2); exchange(3, 4); exchange(5, 6);
+    }
+};
+
 // stable sort by t == sort by (t, key): insertion sort on a short private list
 __device__ inline void sort_list(double* t, int* key, int n) {
     for (int i = 1; i < n; ++i) {
@@ -1096,6 +1118,13 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V
 }
 
 // The n1/n2 walk of prepare_computations (src/intersection.rs:54-80) over the sorted list up to the hit.
+// The list is collected into per-lane scratch memory (ListSink).  Walking it there is a chain of ~50 dependent memory
+// round trips per ray — insertion sort, then equality class and material of every entry and of every container —
+// and a level's container-walk launch took up to 150 us for 4000 chunks, longer than the level's shadow rays.  So a
+// list of at most SHORT_LIST entries (nearly all of them) is fetched into registers in one go, sorted with a network,
+// what its entries need from memory is requested for all of them at once, and the reference's loop then runs literally
+// on register arrays (`containers` = (class, refractive index) pairs, searched / shifted / appended to with
+// compile-time indices).  Longer lists take the general loop below on the scratch arrays.
 template <int SC, bool COUNT>
 __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M, V3 o, V3 d, double hit_t, int hit_node, Work& w,
                                                double& n1_out, double& n2_out, unsigned& flags, bool alive) {
@@ -1105,31 +1134,93 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
     traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
     flags |= sink.flags;
-    int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
-    sort_list(lt, lk, n);
-    int containers[CONTAINER_CAP];
-    int nc = 0;
-    double n1 = 0., n2 = 0.;
+    const int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     const int hit_cls = alive ? S.node_eq_class[hit_node] : -1;
-    for (int i = 0; i < n; ++i) {
-        int node = lk[i] >> 2;
-        int cls = S.node_eq_class[node];
-        bool is_self = near_eq(lt[i], hit_t) && cls >= 0 && cls == hit_cls;  // Intersection::eq (F6, F14)
-        if (is_self) n1 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-        int found = -1;
-        for (int k = 0; k < nc; ++k) {
-            int ck = S.node_eq_class[containers[k]];
-            if (ck >= 0 && ck == cls) { found = k; break; }
+    double n1 = 0., n2 = 0.;
+    const bool is_short = n <= SHORT_LIST;
+    if (is_short) {
+        ShortList L;
+        int cls[SHORT_LIST];
+        double ior[SHORT_LIST];
+#pragma unroll
+        for (int i = 0; i < SHORT_LIST; ++i) {
+            L.t[i] = INFINITY;
+            L.key[i] = 0x7fffffff;
+            if (i < n) { L.t[i] = lt[i]; L.key[i] = lk[i]; }
         }
-        if (found >= 0) {
-            for (int k = found; k + 1 < nc; ++k) containers[k] = containers[k + 1];
-            --nc;
-        } else if (nc < CONTAINER_CAP) {
-            containers[nc++] = node;
-        } else {
-            flags |= RT_FLAG_LIST_OVERFLOW;
+        L.sort();
+#pragma unroll
+        for (int i = 0; i < SHORT_LIST; ++i) {
+            cls[i] = -1;
+            ior[i] = 1.;
+            if (i < n) {
+                const int node = L.key[i] >> 2;
+                cls[i] = S.node_eq_class[node];
+                ior[i] = S.mat[(size_t)S.node_material[node] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+            }
         }
-        if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        int ccls[SHORT_LIST];     // containers: equality class ...
+        double cior[SHORT_LIST];  // ... and refractive index of each
+#pragma unroll
+        for (int k = 0; k < SHORT_LIST; ++k) { ccls[k] = -1; cior[k] = 1.; }
+        int nc = 0;
+#pragma unroll
+        for (int i = 0; i < SHORT_LIST; ++i) {
+            if (i < n) {
+                const bool is_self = near_eq(L.t[i], hit_t) && cls[i] >= 0 && cls[i] == hit_cls;  // Intersection::eq (F6, F14)
+                double last = 1.;  // containers.last()'s refractive index, 1.0 when empty (src/intersection.rs:57-62)
+#pragma unroll
+                for (int k = 0; k < SHORT_LIST; ++k)
+                    if (k == nc - 1) last = cior[k];
+                if (is_self) n1 = last;
+                int found = -1;  // position() of the first equal container (src/intersection.rs:65)
+#pragma unroll
+                for (int k = SHORT_LIST - 1; k >= 0; --k)
+                    if (k < nc && ccls[k] >= 0 && ccls[k] == cls[i]) found = k;
+                if (found >= 0) {
+#pragma unroll
+                    for (int k = 0; k + 1 < SHORT_LIST; ++k)
+                        if (k >= found) { ccls[k] = ccls[k + 1]; cior[k] = cior[k + 1]; }
+                    --nc;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < SHORT_LIST; ++k)
+                        if (k == nc) { ccls[k] = cls[i]; cior[k] = ior[i]; }
+                    ++nc;
+                }
+                if (is_self) {
+                    double last2 = 1.;
+#pragma unroll
+                    for (int k = 0; k < SHORT_LIST; ++k)
+                        if (k == nc - 1) last2 = cior[k];
+                    n2 = last2;
+                }
+            }
+        }
+    } else {
+        sort_list(lt, lk, n);
+        int containers[CONTAINER_CAP];
+        int nc = 0;
+        for (int i = 0; i < n; ++i) {
+            int node = lk[i] >> 2;
+            int cls = S.node_eq_class[node];
+            bool is_self = near_eq(lt[i], hit_t) && cls >= 0 && cls == hit_cls;  // Intersection::eq (F6, F14)
+            if (is_self) n1 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+            int found = -1;
+            for (int k = 0; k < nc; ++k) {
+                int ck = S.node_eq_class[containers[k]];
+                if (ck >= 0 && ck == cls) { found = k; break; }
+            }
+            if (found >= 0) {
+                for (int k = found; k + 1 < nc; ++k) containers[k] = containers[k + 1];
+                --nc;
+            } else if (nc < CONTAINER_CAP) {
+                containers[nc++] = node;
+            } else {
+                flags |= RT_FLAG_LIST_OVERFLOW;
+            }
+            if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        }
     }
     n1_out = n1;
     n2_out = n2;
