@@ -137,8 +137,9 @@ def main():
     n_max = max(counts)
     shard = torch.zeros((n_max, 3), dtype=torch.float64, device=dev)
     frame = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-    gathered = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(world)] if (rank == 0 and world > 1) else None
-    packed = torch.zeros((sum(counts), 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+    # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
+    gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+    gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
     opts = rt.RenderOpts(max_depth=args.depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
 
     def step(stats=None):
@@ -153,19 +154,10 @@ def main():
                                     C.byref(stats) if stats is not None else None)
         if rc < 0:
             raise RuntimeError(rt.last_error())
-        if world > 1:
-            dist.gather(shard, gathered, dst=0)          # RCCL gather over xGMI: no reduction, peers -> root
-            if rank == 0:
-                off = 0
-                for r in range(world):
-                    packed[off:off + counts[r]] = gathered[r][:counts[r]]
-                    off += counts[r]
-                src = packed
-        else:
-            src = shard
+        dist.gather(shard, gathered, dst=0)              # RCCL gather over xGMI: no reduction, peers -> root
+        torch.cuda.synchronize()                         # every rank: the library's stream rewrites `shard` next frame
         if rank == 0:
-            torch.cuda.synchronize()
-            rc = rt.lib.rt_assemble(scene, C.byref(cd), world, src.data_ptr(), None, frame.data_ptr(), None, None)
+            rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None, None)
             if rc < 0:
                 raise RuntimeError(rt.last_error())
 

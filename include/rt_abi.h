@@ -277,6 +277,14 @@ int rt_render_frame(rt_scene* scene, const rt_camera_desc* camera, const rt_rend
 int rt_assemble(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const double* d_rgb_shards,
                 const int32_t* d_hit_id_shards, double* d_rgb_frame, int32_t* d_hit_id_frame, void* stream);
 
+/* The same for shards that sit `shard_stride` pixels apart instead of back to back (shard r starts at pixel
+ * r * shard_stride of d_rgb_shards / d_hit_id_shards) — the layout an RCCL gather of equally sized, padded buffers
+ * leaves on the root, so that no repacking is needed between the gather and this call.  shard_stride == 0: back to
+ * back, as rt_assemble.  Part of the same replacement of Canvas::write_pixel's loop (src/camera.rs:65-71). */
+int rt_assemble_strided(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const double* d_rgb_shards,
+                        const int32_t* d_hit_id_shards, int64_t shard_stride, double* d_rgb_frame,
+                        int32_t* d_hit_id_frame, void* stream);
+
 /* World::color_at (src/world.rs:81-90) for a batch of arbitrary rays, host buffers.
  *   origins, directions [n_rays][3]; rgb_out [n_rays][3]; hit_id_out / flags_out nullable [n_rays]. */
 int rt_color_at(rt_scene* scene, int64_t n_rays, const double* origins, const double* directions, int32_t remaining,

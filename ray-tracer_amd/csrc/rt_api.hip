@@ -842,8 +842,14 @@ int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
 
 int rt_assemble(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const double* d_rgb_shards, const int32_t* d_id_shards,
                 double* d_rgb_frame, int32_t* d_id_frame, void* stream) {
+    return rt_assemble_strided(s, cam, n_ranks, d_rgb_shards, d_id_shards, 0, d_rgb_frame, d_id_frame, stream);
+}
+
+int rt_assemble_strided(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const double* d_rgb_shards, const int32_t* d_id_shards,
+                        int64_t shard_stride, double* d_rgb_frame, int32_t* d_id_frame, void* stream) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
     if (!cam || !d_rgb_shards || !d_rgb_frame) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    if (shard_stride < 0) { rt_set_error("negative shard stride"); return RT_ERR_BAD_ARG; }
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
     size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
     HIP_TRY(hipMemsetAsync(d_rgb_frame, 0, npx * 3 * sizeof(double), st));
@@ -854,11 +860,12 @@ int rt_assemble(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const d
         long long n_slots = 0, n_valid = 0;
         int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid);
         if (rc != RT_OK) return rc;
+        if (shard_stride > 0 && n_slots > shard_stride) { rt_set_error("shard %d holds %lld pixels, the stride is %lld", r, n_slots, (long long)shard_stride); return RT_ERR_BAD_ARG; }
         if (n_slots)
             hipLaunchKernelGGL(k_assemble, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, d_rgb_shards + 3 * off,
                                d_id_shards ? d_id_shards + off : nullptr, (const uint8_t*)nullptr, d_rgb_frame, d_id_frame,
                                (uint8_t*)nullptr);
-        off += n_slots;
+        off += shard_stride > 0 ? (long long)shard_stride : n_slots;
     }
     HIP_TRY(hipGetLastError());
     if (!stream) HIP_TRY(hipStreamSynchronize(st));

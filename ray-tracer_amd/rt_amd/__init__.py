@@ -103,7 +103,7 @@ class CMaterial(C.Structure):  # rth_material
 
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
-               "rt_render_shard", "rt_render_frame", "rt_assemble", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
+               "rt_render_shard", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
                "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
@@ -129,6 +129,8 @@ lib.rt_render_frame.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Ren
                                 C.c_void_p, C.POINTER(Stats)]
 lib.rt_assemble.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p]
+lib.rt_assemble_strided.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
 lib.rt_color_at.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, c_ip, c_bp, C.POINTER(Stats)]
 lib.rt_intersect_world.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_ip, c_dp, c_ip]
 lib.rt_is_shadowed.argtypes = [C.c_void_p, C.c_int64, c_dp, c_bp]

@@ -1,5 +1,5 @@
 """world_size-2 (and 3) gloo rehearsal of the multi-GPU plumbing bench.py uses: tile-shard the frame, gather the
-shards to rank 0, pack, assemble.  Runs on CPU: the shards are filled with a function of the pixel instead of being
+shards to rank 0 (one padded buffer, strided), assemble.  Runs on CPU: the shards are filled with a function of the pixel instead of being
 rendered, so what is tested is the partition (rt_shard_pixel_count / slot->pixel map) and the collective."""
 import ctypes as C
 import math
@@ -29,10 +29,12 @@ def _worker(rank, world, port, hsize, vsize, out_path):
     shard = np.zeros((n_max, 3))
     shard[: len(px)][valid] = _value(px[valid], py[valid])
     t = torch.from_numpy(shard)
-    gathered = [torch.zeros((n_max, 3), dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    # as bench.py: the root gathers into views of ONE [world, n_max, 3] buffer (what rt_assemble_strided reads in place)
+    gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64) if rank == 0 else None
+    gathered = list(gathered_all.unbind(0)) if rank == 0 else None
     dist.gather(t, gathered, dst=0)
     if rank == 0:
-        frame = rt.assemble_host(cd, world, [g.numpy()[: counts[r]] for r, g in enumerate(gathered)])
+        frame = rt.assemble_host(cd, world, [gathered_all[r].numpy()[: counts[r]] for r in range(world)])
         np.save(out_path, frame)
     dist.barrier()
     dist.destroy_process_group()

@@ -345,6 +345,22 @@ def test_device_shard_path_matches_host_path():
     assert rt.lib.rt_assemble(w.scene(), C.byref(cd), n_ranks, rgb.data_ptr(), ids.data_ptr(), frame.data_ptr(), fid.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(frame.cpu().numpy(), full.rgb) and np.array_equal(fid.cpu().numpy(), full.hit_id)
+    # the same from padded shards a fixed stride apart (what an RCCL gather of equal buffers leaves on the root)
+    stride = max(counts) + 37
+    padded = torch.full((n_ranks, stride, 3), -3.0, dtype=torch.float64, device=dev)
+    padded_ids = torch.full((n_ranks, stride), -3, dtype=torch.int32, device=dev)
+    for r in range(n_ranks):
+        padded[r, :counts[r]] = shards[r][0]
+        padded_ids[r, :counts[r]] = shards[r][1]
+    frame.fill_(-1.0)
+    fid.fill_(-1)
+    torch.cuda.synchronize()
+    assert rt.lib.rt_assemble_strided(w.scene(), C.byref(cd), n_ranks, padded.data_ptr(), padded_ids.data_ptr(), stride,
+                                      frame.data_ptr(), fid.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full.rgb) and np.array_equal(fid.cpu().numpy(), full.hit_id)
+    assert rt.lib.rt_assemble_strided(w.scene(), C.byref(cd), n_ranks, padded.data_ptr(), padded_ids.data_ptr(), 5,
+                                      frame.data_ptr(), fid.data_ptr(), None) < 0  # stride smaller than a shard
     # and the host mirror of the scatter agrees with the device scatter
     host = rt.assemble_host(cd, n_ranks, [s[0].cpu().numpy() for s in shards])
     assert np.array_equal(host, full.rgb)
