@@ -482,7 +482,8 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     }
     if (n_slots == 0) return RT_OK;
     // ---- several sub-frame chains in flight (only the plain path: no stats, no instrumentation)
-    const int K = int(std::min<long long>(s->max_chains, std::max<long long>(1, n_slots / 65536)));
+    // measured per shard size on the 1080p frame: 259k slots 1.09 ms with one chain / 1.17 with two, 518k 1.28 / 1.22
+    const int K = int(std::min<long long>(s->max_chains, std::max<long long>(1, n_slots / 256000)));
     if (!stats && !opts->want_counters) {
         const int D = opts->max_depth;
         CameraParams ck[rt_scene::MAX_CHAINS];
