@@ -264,6 +264,12 @@ int64_t rt_shard_pixel_count(const rt_camera_desc* camera, int32_t rank, int32_t
 int rt_render_shard(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_out,
                     int32_t* d_hit_id_out, uint8_t* d_flags_out, rt_stats* stats_out);
 
+/* How many triangle meshes of the scene got their BVH topology from the GPU build (Morton sort + binary radix tree,
+ * csrc/rt_lbvh.hip; opt-in with RT_AMD_DEVICE_BVH=1, meshes of 1024 triangles and more) rather than the host's binned
+ * SAH.  No counterpart in the reference (its groups have no acceleration for triangles): this is the "what was built"
+ * read-back for SURVEY.md section 8(f) row 1. */
+int32_t rt_scene_meshes_built_on_gpu(const rt_scene* scene);
+
 /* Camera::render (src/camera.rs:62-74) with the Canvas left in DEVICE memory: d_rgb_frame [vsize*hsize*3] row-major
  * (Canvas::write_pixel layout, src/canvas.rs:25-27), d_hit_id_frame / d_flags_frame nullable [vsize*hsize].  The
  * pixels of shard opts->rank of opts->n_ranks are written where they belong in the frame, the never-rendered last row

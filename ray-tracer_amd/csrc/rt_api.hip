@@ -56,6 +56,7 @@ struct rt_scene {
     DScene ds{};
     std::vector<void*> allocs;
     bool has_csg = false, has_smooth = false, any_transparent = false;
+    int meshes_built_on_gpu = 0;
     int scene_class = 0;  // SC_CSG | SC_CULL: which traversal kernel variants this scene runs
     int n_lights = 0;
     std::vector<LevelStore> levels;
@@ -635,7 +636,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     *out = nullptr;
     Program prog;
     std::string err;
-    int rc = compile_program(*desc, prog, err);
+    const int ndev0 = rt_device_count();
+    int rc = compile_program(*desc, prog, err, device >= 0 && device < ndev0 ? device : -1);
     if (rc != RT_OK) { rt_set_error("%s", err.c_str()); return rc; }
     if (prog.max_chain > MAX_CHAIN) { rt_set_error("transform chain deeper than %d levels", MAX_CHAIN); return RT_ERR_UNSUPPORTED; }
     int ndev = rt_device_count();
@@ -733,6 +735,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         double ri = d.material_params[size_t(m) * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
         if (!(std::isfinite(ri) && ri > 0.)) s->ds.walk_at_zero = 1;
     }
+    s->meshes_built_on_gpu = prog.meshes_built_on_gpu;
     s->has_csg = prog.has_csg;
     s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0);
     s->has_smooth = prog.has_smooth;
@@ -813,6 +816,8 @@ int rt_render_shard(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
     if (!opts->stream) HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
 }
+
+int32_t rt_scene_meshes_built_on_gpu(const rt_scene* s) { return s ? s->meshes_built_on_gpu : 0; }
 
 int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
                     uint8_t* d_flags_frame, rt_stats* stats) {

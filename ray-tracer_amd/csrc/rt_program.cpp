@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <unordered_map>
 #include <unordered_set>
 
 namespace rt {
@@ -21,6 +22,8 @@ struct Compiler {
     Program& p;
     std::map<std::vector<int32_t>, int32_t> chain_index;
     std::map<std::pair<int32_t, int32_t>, int32_t> nchain_index;
+
+    int build_device = -1;  // >= 0 and RT_AMD_DEVICE_BVH=1: tree topology of large meshes from the GPU (rt_lbvh.hip)
 
     Compiler(const rt_scene_desc& desc, Program& prog) : d(desc), p(prog) {}
 
@@ -194,6 +197,33 @@ struct Compiler {
         return me;
     }
 
+    // ---- tree topology from the GPU build ----------------------------------------------------------------
+    struct Lbvh {
+        std::vector<int32_t> left, right, first, last;
+    };
+    // Node i of the radix tree over `sorted` -> child reference + padded box, as build() returns them.  A node of at
+    // most BVH_LEAF_MAX triangles becomes a leaf; a subtree that would not fit the depth bound is rebuilt by build().
+    int32_t from_lbvh(const Lbvh& t, std::vector<TriRef>& sorted, int32_t ref, Box& box, int depth) {
+        size_t lo, hi;  // positions [lo, hi)
+        if (ref < 0) { lo = size_t(~ref); hi = lo + 1; }
+        else { lo = size_t(t.first[size_t(ref)]); hi = size_t(t.last[size_t(ref)]) + 1; }
+        const size_t n = hi - lo;
+        int lg = 0;
+        while ((size_t(1) << lg) < n) ++lg;
+        if (ref < 0 || n <= size_t(BVH_LEAF_MAX) || depth + lg + 3 >= BVH2_MAX_DEPTH) return build(sorted, lo, hi, box, depth);
+        int32_t me = int32_t(n2.size());
+        n2.emplace_back();
+        Box b0, b1;
+        int32_t c0 = from_lbvh(t, sorted, t.left[size_t(ref)], b0, depth + 1);
+        int32_t c1 = from_lbvh(t, sorted, t.right[size_t(ref)], b1, depth + 1);
+        Node2& nd = n2[size_t(me)];
+        nd.box[0] = b0; nd.box[1] = b1;
+        nd.child[0] = c0; nd.child[1] = c1;
+        box = b0;
+        box.add(b1.lo, b1.hi);
+        return me;
+    }
+
     static float round_down(double x) {
         float f = float(x);
         if (double(f) > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
@@ -257,12 +287,20 @@ struct Compiler {
             struct Key {
                 double v[9];
                 int32_t kind;
-                bool operator<(const Key& o) const {
-                    int c = std::memcmp(v, o.v, sizeof v);
-                    return c != 0 ? c < 0 : kind < o.kind;
+                bool operator==(const Key& o) const { return std::memcmp(v, o.v, sizeof v) == 0 && kind == o.kind; }
+            };
+            struct KeyHash {
+                size_t operator()(const Key& k) const {  // FNV-1a over the bit patterns
+                    uint64_t h = 1469598103934665603ull;
+                    const unsigned char* b = reinterpret_cast<const unsigned char*>(k.v);
+                    for (size_t i = 0; i < sizeof k.v; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+                    h ^= uint64_t(uint32_t(k.kind));
+                    h *= 1099511628211ull;
+                    return size_t(h);
                 }
             };
-            std::map<Key, size_t> seen;
+            std::unordered_map<Key, size_t, KeyHash> seen;
+            seen.reserve(all_tri_nodes.size());
             std::vector<std::vector<int32_t>> extra;
             for (int32_t node : all_tri_nodes) {
                 int32_t t = d.node_param[node];
@@ -301,7 +339,37 @@ struct Compiler {
         pad = 1e-7 * maxabs + 1e-300;
         n2.clear();
         Box rb;
-        int32_t root = build(refs, 0, refs.size(), rb, 0);
+        int32_t root = 0;
+        bool from_gpu = false;
+        const char* env = std::getenv("RT_AMD_DEVICE_BVH");
+        if (build_device >= 0 && env && env[0] == '1' && refs.size() >= size_t(LBVH_MIN_TRIANGLES)) {
+            Box all;
+            all.reset();
+            std::vector<double> cen(refs.size() * 3);
+            for (size_t i = 0; i < refs.size(); ++i) {
+                all.add(refs[i].c, refs[i].c);
+                for (int k = 0; k < 3; ++k) cen[3 * i + size_t(k)] = refs[i].c[k];
+            }
+            Lbvh t;
+            std::vector<int32_t> order;
+            if (lbvh_topology(build_device, refs.size(), cen.data(), all.lo, all.hi, order, t.left, t.right, t.first, t.last)) {
+                std::vector<TriRef> sorted(refs.size());
+                std::vector<char> seen(refs.size(), 0);
+                bool ok = true;
+                for (size_t q = 0; q < order.size() && ok; ++q) {
+                    const size_t i = size_t(order[q]);
+                    ok = order[q] >= 0 && i < refs.size() && !seen[i];
+                    if (ok) { seen[i] = 1; sorted[q] = refs[i]; }
+                }
+                if (ok) {
+                    root = from_lbvh(t, sorted, 0, rb, 0);
+                    refs.swap(sorted);
+                    from_gpu = true;
+                    ++p.meshes_built_on_gpu;
+                }
+            }
+        }
+        if (!from_gpu) root = build(refs, 0, refs.size(), rb, 0);
         last_mesh_box = rb;
         if (root < 0) {  // the whole mesh is one leaf: wrap it in a node
             Node2 nd;
@@ -684,10 +752,11 @@ int validate(const rt_scene_desc& d, std::string& err) {
 
 }  // namespace
 
-int compile_program(const rt_scene_desc& d, Program& out, std::string& err) {
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err, int build_device) {
     int rc = validate(d, err);
     if (rc != RT_OK) return rc;
     Compiler c(d, out);
+    c.build_device = build_device;
     // chain 0 = the empty chain
     c.chain_offset({});
     out.node_nchain.assign(size_t(d.n_nodes), -1);

@@ -77,6 +77,7 @@ struct Program {
     std::vector<int32_t> mesh_dups;    // node lists of repeated triangles (MeshTri::smooth)
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
+    int32_t meshes_built_on_gpu = 0;   // meshes whose tree topology came from rt_lbvh.hip
     bool has_cull = false;             // the program has ITEM_CULL ranges
     bool has_smooth = false;
     bool all_cast_shadow = true;
@@ -86,8 +87,19 @@ struct Program {
 
 // Validates the descriptor (pointers, index ranges, affine inverses, CSG operand ids) and compiles it.
 // Returns RT_OK or an RT_ERR_* code with `err` set.
-int compile_program(const rt_scene_desc& d, Program& out, std::string& err);
+// `build_device` >= 0: meshes of at least LBVH_MIN_TRIANGLES triangles take their tree topology from the GPU build
+// (rt_lbvh.hip) on that device when RT_AMD_DEVICE_BVH=1; everything else, and any mesh the GPU build fails on, uses
+// the host's binned-SAH build.
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err, int build_device = -1);
 
+// rt_lbvh.hip: Morton sort + binary radix tree of n >= 2 centroids on the GPU.  order[p] = index of the triangle at
+// sorted position p; internal node i covers positions first[i]..last[i] and has children left[i], right[i] (>= 0:
+// internal node, < 0: ~position).  Node 0 is the root.  false: not built (the caller uses the host build).
+bool lbvh_topology(int device, size_t n, const double* centroids, const double* box_lo, const double* box_hi,
+                   std::vector<int32_t>& order, std::vector<int32_t>& left, std::vector<int32_t>& right,
+                   std::vector<int32_t>& first, std::vector<int32_t>& last);
+
+constexpr int LBVH_MIN_TRIANGLES = 1024; // smaller meshes are always built on the host
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
 constexpr int BVH_LEAF_MAX = 4;        // triangles per leaf (measured: 1 -> 2.74 ms, 2 -> 2.21 ms, 4 -> 2.12 ms per frame); fetched two at a time
 constexpr int BVH_STACK = 32;          // device traversal stack entries per ray: 3 pending siblings per BVH4 level

@@ -416,6 +416,38 @@ def test_world_space_cull_ranges_change_nothing(monkeypatch):
     assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
 
 
+def test_gpu_built_bvh_changes_nothing(monkeypatch):
+    """RT_AMD_DEVICE_BVH=1: meshes of 1024+ triangles take their tree topology from the GPU (Morton sort + binary radix
+    tree, csrc/rt_lbvh.hip).  A BVH only decides which triangles get tested: renders are bit-identical to those with the
+    host's SAH tree, lists and shadows match the oracle, and the scene reports that the GPU build was used."""
+    w0, cam0 = scenes.teapot_scene(480, 270)
+    plain = cam0.render(w0)
+    assert rt.lib.rt_scene_meshes_built_on_gpu(w0.scene()) == 0
+    monkeypatch.setenv("RT_AMD_DEVICE_BVH", "1")
+    for builder, size, depth in ((scenes.teapot_scene, (480, 270), 5), (scenes.smooth_teapot_alone, (240, 135), 5),
+                                 (lambda w, h: scenes.instanced_grid(w, h, grid=2), (320, 180), 6)):
+        w1, cam1 = builder(*size)
+        img = cam1.render(w1, depth)
+        assert rt.lib.rt_scene_meshes_built_on_gpu(w1.scene()) >= 1
+        monkeypatch.setenv("RT_AMD_DEVICE_BVH", "0")
+        w2, cam2 = builder(*size)
+        ref = cam2.render(w2, depth)
+        monkeypatch.setenv("RT_AMD_DEVICE_BVH", "1")
+        shift = int(img.hit_id[img.hit_id > 0].min()) - int(ref.hit_id[ref.hit_id > 0].min())
+        assert np.array_equal(np.where(img.hit_id > 0, img.hit_id - shift, 0), ref.hit_id)
+        assert np.array_equal(img.rgb, ref.rgb, equal_nan=True) and np.array_equal(img.flags, ref.flags)
+        assert img.stats.total_rays == ref.stats.total_rays
+    w, cam = scenes.teapot_scene(96, 54)
+    assert_image_parity(w, cam)
+    assert rt.lib.rt_scene_meshes_built_on_gpu(w.scene()) == 1
+    o, d = _random_rays(1500, 11, center=(0., 1.5, 0.), radius=9.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
+    del plain
+
+
 def test_instrumented_counters_do_not_change_the_image():
     w, cam = scenes.teapot_scene(160, 90)
     a = cam.render(w)
