@@ -321,6 +321,27 @@ def test_full_size_properties_c3():
     assert float(np.abs(a.rgb[ys, xs] - o.rgb[ys, xs]).max()) < COLOR_TOL
 
 
+def test_full_size_properties_c4_and_c5():
+    """BASELINE configs 4 (2560x1440) and 5 (7680x4320, depth 8, here with a 2x2 grid to keep the oracle sample cheap):
+    the oracle on a sparse pixel sample of the SAME full-size frames, F1, ray accounting, determinism."""
+    for builder, (wd, ht), depth, stride in ((scenes.mixed_scene, (2560, 1440), 5, 61),
+                                             (lambda w, h: scenes.instanced_grid(w, h, grid=2), (7680, 4320), 8, 331)):
+        w, cam = builder(wd, ht)
+        a = cam.render(w, depth)
+        assert not a.rgb[-1].any() and not a.rgb[:, -1].any()
+        assert a.stats.rays_primary == (wd - 1) * (ht - 1)
+        assert a.stats.rays_shadow == a.stats.shaded_nodes * len(w.lights)
+        b = cam.render(w, depth, want_stats=False)
+        assert np.array_equal(a.rgb, b.rgb, equal_nan=True) and np.array_equal(a.hit_id, b.hit_id) and np.array_equal(a.flags, b.flags)
+        o = ob.render(w, cam, depth, stride=stride)
+        ys, xs = np.mgrid[0:ht - 1:stride, 0:wd - 1:stride]
+        assert np.array_equal(a.hit_id[ys, xs], o.hit_id[ys, xs])
+        assert np.array_equal(a.flags[ys, xs], o.flags[ys, xs])
+        err = np.abs(a.rgb[ys, xs] - o.rgb[ys, xs])
+        err[np.isnan(a.rgb[ys, xs]) & np.isnan(o.rgb[ys, xs])] = 0.
+        assert float(err.max()) < COLOR_TOL
+
+
 def test_device_shard_path_matches_host_path():
     import torch
     w, cam = scenes.mixed_scene(200, 120)
