@@ -260,7 +260,11 @@ int64_t rt_shard_pixel_count(const rt_camera_desc* camera, int32_t rank, int32_t
 
 /* One shard of Camera::render with DEVICE output pointers (for one-process-per-GPU drivers that gather the
  * shards with RCCL).  d_rgb_out [count*3], d_hit_id_out nullable [count], d_flags_out nullable [count], in
- * shard-local pixel order; count = rt_shard_pixel_count().  Asynchronous on opts->stream when stats_out is NULL. */
+ * shard-local pixel order; count = rt_shard_pixel_count().  All work is ordered on opts->stream (the scene's own
+ * stream when that is NULL).  The call returns once the shard's ray tree has been walked — the host reads the
+ * per-level ray counts to learn whether a queue has to grow — so it is not a fire-and-forget enqueue; with a caller
+ * stream the output writes are complete or ordered on that stream, and work enqueued on it afterwards (an RCCL
+ * gather, rt_assemble) sees them without a host wait; with the scene's stream the call waits for them. */
 int rt_render_shard(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_out,
                     int32_t* d_hit_id_out, uint8_t* d_flags_out, rt_stats* stats_out);
 
@@ -274,7 +278,8 @@ int32_t rt_scene_meshes_built_on_gpu(const rt_scene* scene);
  * (Canvas::write_pixel layout, src/canvas.rs:25-27), d_hit_id_frame / d_flags_frame nullable [vsize*hsize].  The
  * pixels of shard opts->rank of opts->n_ranks are written where they belong in the frame, the never-rendered last row
  * and column (F1) are cleared, everything else is left alone: with n_ranks == 1 this is the whole render, one call and
- * no intermediate copy; ranks of one process may also fill one frame in turn.  Blocking unless opts->stream is set. */
+ * no intermediate copy; ranks of one process may also fill one frame in turn.  Stream ordering and blocking as for
+ * rt_render_shard. */
 int rt_render_frame(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_frame,
                     int32_t* d_hit_id_frame, uint8_t* d_flags_frame, rt_stats* stats_out);
 

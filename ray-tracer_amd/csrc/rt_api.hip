@@ -109,6 +109,25 @@ struct ChainScope {
     }
 };
 
+// A device allocation / a pair of timing events that live for one call.
+struct DeviceTemp {
+    void* p = nullptr;
+    DeviceTemp() = default;
+    DeviceTemp(const DeviceTemp&) = delete;
+    DeviceTemp& operator=(const DeviceTemp&) = delete;
+    ~DeviceTemp() { if (p) (void)hipFree(p); }
+};
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
 int grow(GrowBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return RT_OK;
     if (b.p) HIP_TRY(hipFree(b.p));
@@ -585,11 +604,11 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         }
         return RT_OK;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair whole;
     if (stats) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, st));
+        HIP_TRY(hipEventCreate(&whole.e0));
+        HIP_TRY(hipEventCreate(&whole.e1));
+        HIP_TRY(hipEventRecord(whole.e0, st));
     }
     rc = ensure_level(s, 0, n_slots);
     if (rc != RT_OK) return rc;
@@ -602,13 +621,11 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (stats) {
-        HIP_TRY(hipEventRecord(e1, st));
-        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventRecord(whole.e1, st));
+        HIP_TRY(hipEventSynchronize(whole.e1));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&ms, whole.e0, whole.e1));
         stats->ms_total = ms;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     return RT_OK;
 }
@@ -1042,20 +1059,19 @@ int rt_ray_for_pixel(const rt_camera_desc* cam, int64_t n, const int32_t* px, co
     if (n == 0) return RT_OK;
     if (rt_device_count() <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(0));
-    int32_t *dpx = nullptr, *dpy = nullptr;
-    double *dor = nullptr, *ddi = nullptr;
     size_t ib = size_t(n) * sizeof(int32_t), db = size_t(n) * 3 * sizeof(double);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dpx), ib));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dpy), ib));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dor), db));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ddi), db));
-    HIP_TRY(hipMemcpy(dpx, px, ib, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dpy, py, ib, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_rays_for_pixels, dim3(blocks_for(n)), dim3(BLOCK), 0, nullptr, c, (long long)n, dpx, dpy, dor, ddi);
+    DeviceTemp dpx, dpy, dor, ddi;  // freed on every way out
+    HIP_TRY(hipMalloc(&dpx.p, ib));
+    HIP_TRY(hipMalloc(&dpy.p, ib));
+    HIP_TRY(hipMalloc(&dor.p, db));
+    HIP_TRY(hipMalloc(&ddi.p, db));
+    HIP_TRY(hipMemcpy(dpx.p, px, ib, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dpy.p, py, ib, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rays_for_pixels, dim3(blocks_for(n)), dim3(BLOCK), 0, nullptr, c, (long long)n, static_cast<const int32_t*>(dpx.p),
+                       static_cast<const int32_t*>(dpy.p), static_cast<double*>(dor.p), static_cast<double*>(ddi.p));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(origins_out, dor, db, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(directions_out, ddi, db, hipMemcpyDeviceToHost));
-    (void)hipFree(dpx); (void)hipFree(dpy); (void)hipFree(dor); (void)hipFree(ddi);
+    HIP_TRY(hipMemcpy(origins_out, dor.p, db, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(directions_out, ddi.p, db, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
