@@ -752,6 +752,14 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         double ri = d.material_params[size_t(m) * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
         if (!(std::isfinite(ri) && ri > 0.)) s->ds.walk_at_zero = 1;
     }
+    // F14: a leaf that is not equal to itself (an unbounded cylinder or cone: near_eq(inf, inf) is false) is never found
+    // by the n1/n2 walk, which leaves n1 = n2 = 0 and makes schlick 0/0 = NaN — and NaN * BLACK is NaN, not BLACK
+    for (int n = 0; n < d.n_nodes; ++n)
+        if (d.node_kind[n] != RT_GROUP && d.node_kind[n] != RT_CSG && d.node_eq_class[n] < 0) s->ds.walk_at_zero = 1;
+    if (std::getenv("RT_AMD_VERBOSE"))
+        std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items, %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
+                     d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),
+                     (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0));
     s->meshes_built_on_gpu = prog.meshes_built_on_gpu;
     s->has_csg = prog.has_csg;
     s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0);

@@ -9,9 +9,15 @@ namespace rt {
 
 constexpr double EPS = 0.00001;   // EPSILON, src/lib.rs:42
 constexpr int BLOCK = 256;        // 4 wavefronts: streaming kernels
-constexpr int TBLOCK = 1024;      // 16 wavefronts: traversal kernels (they share one LDS copy of the BVH top levels)
+#ifndef RT_TBLOCK
+#define RT_TBLOCK 1024
+#endif
+#ifndef RT_LDS_NODE_CAP
+#define RT_LDS_NODE_CAP 895
+#endif
+constexpr int TBLOCK = RT_TBLOCK;      // 16 wavefronts: traversal kernels (they share one LDS copy of the BVH top levels)
 constexpr int LDS_STACK = 12;     // traversal stack entries per lane kept in LDS; deeper entries spill to HBM (rare)
-constexpr int LDS_NODE_CAP = 895; // BVH4 nodes staged in LDS: ~112 KiB + 48 KiB of per-lane stacks + the feed word <= 160 KiB
+constexpr int LDS_NODE_CAP = RT_LDS_NODE_CAP; // BVH4 nodes staged in LDS: ~112 KiB + 48 KiB of per-lane stacks + the feed word <= 160 KiB
 constexpr int FEED_PARTS = 8;     // chunk-feed counters per traversal kernel, one cache line each
 constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
@@ -64,8 +70,8 @@ struct DScene {
     const double* mesh_box;           // [n_meshes][6] padded f64 box of each mesh (ITEM_MESH.b indexes it)
     int32_t all_cast_shadow;
     int32_t n_lds;                    // BVH nodes [0, n_lds) are staged in LDS by the traversal kernels
-    int32_t walk_at_zero;             // 1: some refractive index is not finite-positive, so the n1/n2 walk cannot be
-                                      //    skipped at remaining == 0 (see needs_walk)
+    int32_t walk_at_zero;             // 1: some refractive index is not finite-positive, or some leaf is not equal to
+                                      //    itself (F14): the n1/n2 walk cannot be skipped at remaining == 0 (needs_walk)
     int32_t _pad;
     int32_t* spill;                   // [BVH_STACK - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
     long long spill_lanes;

@@ -1266,8 +1266,9 @@ __device__ __forceinline__ bool needs_walk(const DScene& S, double reflective, d
     // n1/n2 are read only by refracted_color and schlick, both behind a transparency test.  At remaining <= 0
     // refracted_color and reflected_color return BLACK before using them (src/world.rs:110,121) and schlick's result
     // only scales those two BLACKs: any FINITE reflectance gives surface + 0 + 0.  It is finite whenever every
-    // refractive index in the scene is finite and positive (S.walk_at_zero == 0), so the walk is skipped there and
-    // k_finish records reflectance 0.
+    // refractive index in the scene is finite and positive and every leaf is equal to itself (F14: one that is not
+    // leaves n1 = n2 = 0 and schlick = NaN) — S.walk_at_zero == 0 — so the walk is skipped there and k_finish records
+    // reflectance 0.
     if (remaining <= 0 && !S.walk_at_zero) return false;
     return !near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.);
 }
@@ -1282,7 +1283,7 @@ __device__ __forceinline__ long long level_count(long long n, const unsigned lon
 
 // `remaining` is the value color_at was called with at this level.
 template <int SC, bool NEED_FIRST, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
+__global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
                                                   unsigned long long* counters) {
     const long long n = level_count(n_cap, n_dev);
     Feed feed;
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(TBLOCK) void k_trace(DScene S, Level L, long long n
             transparency = m[RT_MAT_TRANSPARENCY];
         }
         double u = sink.bu, v = sink.bv;
-        unsigned flags = hit ? sink.flags : 0;
+        unsigned flags = alive ? sink.flags : 0;  // a NaN t panics the reference's sort whether or not anything is hit
         if (NEED_FIRST && hit && rec.kind == RT_SMOOTH_TRIANGLE) {
             if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
             else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
@@ -1458,7 +1459,7 @@ __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(
 // run launches them one at a time to keep their work counters apart).  The container chunks — few, and each one a
 // long latency-bound walk — go first, so that they overlap the bulk of the shadow chunks instead of forming a tail.
 template <int SC, bool COUNT, bool WALK>
-__global__ __launch_bounds__(TBLOCK) void k_secondary(DScene S, Level L, unsigned long long* counters, int phases) {
+__global__ __launch_bounds__(TBLOCK, 4) void k_secondary(DScene S, Level L, unsigned long long* counters, int phases) {
     const long long n_shadow = (phases & 1) ? (long long)counters[CNT_SHADOW_Q] * S.n_lights : 0;
     const long long n_walk = (WALK && (phases & 2)) ? (long long)counters[CNT_CONTAINER_Q] : 0;
     Feed shadow_feed, walk_feed;
@@ -1648,7 +1649,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_
 
 // Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
 template <int SC>
-__global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const double* __restrict__ origins,
+__global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const double* __restrict__ origins,
                                                  const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
                                                  int32_t* id_out) {
     Feed feed;
@@ -1680,7 +1681,7 @@ __global__ __launch_bounds__(TBLOCK) void k_list(DScene S, long long n, const do
 
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
 template <int SC>
-__global__ __launch_bounds__(TBLOCK) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
+__global__ __launch_bounds__(TBLOCK, 4) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
     Feed feed;
     const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
     for (long long c = feed.next(); c >= 0; c = feed.next()) {

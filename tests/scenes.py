@@ -214,3 +214,100 @@ def cover_like_scene(hsize=200, vsize=200):
     cam = Camera(hsize, vsize, 0.785)
     cam.transform = view_transform((-6., 6., -10.), (6., 0., 6.), (-0.45, 1., 0.))
     return w, cam
+
+
+def random_scene(seed, hsize=64, vsize=40):
+    """A seeded random world for the fuzz parity tests: every primitive kind, nested groups, CSG trees of every
+    operation, small flat / smooth triangle fans, patterns with their own transforms, glass, mirrors, objects that
+    cast no shadow, truncated and capped cylinders and cones, sheared transforms, one to three lights.  Transforms
+    keep |det| well above 1e-5 (F11: the reference panics on a non-invertible matrix)."""
+    rng = np.random.RandomState(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    pick = lambda seq: seq[int(rng.randint(len(seq)))]
+    colour = lambda: (u(0., 1.), u(0., 1.), u(0., 1.))
+
+    def transform(spread):
+        m = translate(u(-spread, spread), u(-0.5, 2.5) if spread > 1. else u(-spread, spread), u(-spread, spread))
+        m = m * rotate(u(-PI, PI), pick([Axis.X, Axis.Y, Axis.Z]))
+        if rng.rand() < 0.25:
+            m = m * rt.shear(u(-0.3, 0.3), 0., 0., u(-0.3, 0.3), 0., 0.)
+        if rng.rand() < 0.5:
+            s = u(0.4, 1.6)
+            return m * scale(s, s, s)
+        return m * scale(u(0.4, 1.6), u(0.4, 1.6), u(0.4, 1.6))
+
+    def pattern():
+        kind = pick([Pattern.striped, Pattern.gradient, Pattern.ring, Pattern.checkered, Pattern.ring_gradient])
+        p = kind(colour(), colour())
+        if rng.rand() < 0.7:
+            s = u(0.2, 1.5)
+            p.set_transform(rotate(u(-PI, PI), pick([Axis.X, Axis.Y, Axis.Z])) * scale(s, s, s))
+        return p
+
+    def material():
+        m = Material(color=colour(), ambient=u(0., 0.3), diffuse=u(0.2, 0.9), specular=u(0., 1.),
+                     shininess=pick([10., 50., 200., 300.]), reflective=pick([0., 0., 0.3, 1.]),
+                     transparency=pick([0., 0., 0., 0.6, 1.]), refractive_index=pick([1., 1.3, 1.5, 2.417]))
+        return m.with_pattern(pattern()) if rng.rand() < 0.4 else m
+
+    def conic(shape):
+        if rng.rand() < 0.8:
+            lo = u(-1.5, 0.)
+            shape.set_minimum(lo).set_maximum(lo + u(0.3, 2.))
+            shape.set_closed(bool(rng.rand() < 0.6))
+        return shape
+
+    def primitive():
+        k = int(rng.randint(5))
+        s = (Shape.sphere() if k == 0 else Shape.cube() if k == 1 else conic(Shape.cylinder()) if k == 2
+             else conic(Shape.cone()) if k == 3 else Shape.glass_sphere())
+        return s
+
+    def fan(smooth):
+        g = Shape.group()
+        n = int(rng.randint(3, 9))
+        apex = (u(-0.2, 0.2), u(0.8, 1.4), u(-0.2, 0.2))
+        ring = [(math.cos(2. * PI * i / n) * u(0.8, 1.2), u(-0.1, 0.1), math.sin(2. * PI * i / n) * u(0.8, 1.2)) for i in range(n)]
+        for i in range(n):
+            a, b = ring[i], ring[(i + 1) % n]
+            if smooth:
+                nrm = lambda p: tuple(np.asarray(p) / np.linalg.norm(p))
+                g.add_child(Shape.smooth_triangle(apex, a, b, (0., 1., 0.), nrm(a), nrm(b)))
+            else:
+                g.add_child(Shape.triangle(apex, a, b))
+        return g
+
+    def compound(depth):
+        r = rng.rand()
+        if depth <= 0 or r < 0.45:
+            s = primitive()
+            s.set_transform(transform(0.8))
+            return s
+        if r < 0.7:
+            s = Shape.csg(pick(["union", "intersection", "difference"]), compound(depth - 1), compound(depth - 1))
+        elif r < 0.9:
+            s = Shape.group()
+            for _ in range(int(rng.randint(1, 4))):
+                s.add_child(compound(depth - 1))
+        else:
+            s = fan(False)
+        s.set_transform(transform(0.5))
+        return s
+
+    w = World()
+    for _ in range(int(rng.randint(1, 4))):
+        w.lights.append(Light.point_light((u(-10., 10.), u(4., 12.), u(-12., -2.)), (u(0.3, 1.), u(0.3, 1.), u(0.3, 1.))))
+    if rng.rand() < 0.8:
+        w.objects.append(Shape.plane().set_transform(translate(0., -1.2, 0.)).set_material(material()))
+    smooth_world = rng.rand() < 0.1  # a world of smooth fans only (next to other shapes the reference panics, F5b)
+    for _ in range(int(rng.randint(3, 11))):
+        s = fan(True) if smooth_world else compound(2)
+        s.set_transform(transform(4.))
+        s.set_material(material())
+        if rng.rand() < 0.15:
+            s.set_casts_shadow(False)
+        w.objects.append(s)
+    cam = Camera(hsize, vsize, u(0.6, 1.4))
+    a = u(0., 2. * PI)
+    cam.transform = view_transform((11. * math.cos(a), u(1., 7.), 11. * math.sin(a)), (u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
+    return w, cam
