@@ -89,7 +89,9 @@ extern "C" {
                                     u,v were used instead */
 #define RT_FLAG_NAN_T 2u         /* a NaN t reached a sort: reference panics in partial_cmp().unwrap()
                                     (src/world.rs:52, src/group.rs:59, src/csg.rs:71)                    */
-#define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list (CSG scratch / n1-n2 container walk) overflowed */
+#define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list overflowed: more than 32 intersections pending inside one CSG
+                                  * subtree, or more than 256 at or before the hit in the n1/n2 container walk: the
+                                  * pixel's colour is then not guaranteed */
 
 /*
  * Flattened scene.  `nodes` is the intersection tree exactly as World::intersect_world walks it

@@ -23,8 +23,11 @@ constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
-constexpr int LIST_CAP = 64;      // per-ray list for the n1/n2 container walk and rt_intersect_world
-constexpr int CONTAINER_CAP = 32; // `containers` vector of prepare_computations
+#ifndef RT_LIST_CAP
+#define RT_LIST_CAP 256
+#endif
+constexpr int LIST_CAP = RT_LIST_CAP;      // per-ray list for the n1/n2 container walk and rt_intersect_world
+constexpr int CONTAINER_CAP = LIST_CAP; // `containers` vector of prepare_computations: never longer than the list
 constexpr int MAX_CHAIN = 16;     // transform levels above a leaf
 
 // What prepare_computations needs to know about the hit node, in one 16-byte fetch (the SoA columns below stay for

@@ -13,8 +13,9 @@ import scenes
 seeds = [int(x) for x in sys.argv[1].split(",")]
 W, H = 64, 40
 for seed in seeds:
-    depth = 4 if seed % 3 else 6
-    world, cam = scenes.random_scene(seed, W, H)
+    mesh = len(sys.argv) > 2 and sys.argv[2] == "mesh"
+    depth = (3 if seed % 2 else 5) if mesh else (4 if seed % 3 else 6)
+    world, cam = (scenes.random_mesh_scene if mesh else scenes.random_scene)(seed, W, H)
     g = cam.render(world, depth)
     o = ob.render(world, cam, depth)
     line = [f"seed {seed} depth {depth} objects {len(world.objects)}"]
@@ -29,8 +30,11 @@ for seed in seeds:
     o0 = ob.render(world, cam, 0)
     line.append(f"depth0 flag diffs {int((g0.flags != o0.flags).sum())}")
     print("; ".join(line), flush=True)
-    one = np.argwhere((np.isnan(g.rgb) != np.isnan(o.rgb)).any(axis=-1))
-    for y, x in one[:6]:
+    with np.errstate(invalid="ignore"):
+        bad = (np.isnan(g.rgb) != np.isnan(o.rgb)).any(axis=-1) | (g.flags != o.flags) | (np.nan_to_num(np.abs(g.rgb - o.rgb)) > 1e-9).any(axis=-1)
+    one = np.argwhere(bad)
+    print(f"   stats gpu {g.stats.rays_reflect} {g.stats.rays_refract} {g.stats.rays_shadow} oracle {o.stats.rays_reflect} {o.stats.rays_refract} {o.stats.rays_shadow}; smooth triangles {world.flatten().contents.n_smooth}")
+    for y, x in one[:4]:
         print(f"   pixel ({x},{y}): gpu {g.rgb[y, x]} oracle {o.rgb[y, x]} id {g.hit_id[y, x]}/{o.hit_id[y, x]} flags {g.flags[y, x]}/{o.flags[y, x]}")
         ro, rd = cam.rays_for_pixels(np.array([x], dtype=np.int32), np.array([y], dtype=np.int32))
         for rem in range(depth + 1):

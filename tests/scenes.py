@@ -311,3 +311,85 @@ def random_scene(seed, hsize=64, vsize=40):
     a = u(0., 2. * PI)
     cam.transform = view_transform((11. * math.cos(a), u(1., 7.), 11. * math.sin(a)), (u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
     return w, cam
+
+
+def random_mesh_obj(rng):
+    """OBJ text of a random height field (two triangles per cell), some faces repeated, up to three polygon faces (the
+    parser fans those over the whole vertex list, F3), an optional second named group of loose triangles, optionally
+    with vertex normals on every face."""
+    nx, nz = int(rng.randint(5, 15)), int(rng.randint(5, 15))
+    smooth = rng.rand() < 0.3
+    lines = []
+    for iz in range(nz):
+        for ix in range(nx):
+            lines.append(f"v {ix - (nx - 1) / 2.:.4f} {rng.uniform(0., 1.2):.4f} {iz - (nz - 1) / 2.:.4f}")
+    n_grid = nx * nz
+    n_loose = int(rng.randint(0, 40)) * 3
+    for _ in range(n_loose // 3):
+        c = rng.uniform(-4., 4., size=3) + np.array([0., 3., 0.])
+        for _ in range(3):
+            p = c + rng.uniform(-0.8, 0.8, size=3)
+            lines.append(f"v {p[0]:.4f} {p[1]:.4f} {p[2]:.4f}")
+    if smooth:
+        for _ in range(n_grid + n_loose):
+            n = rng.normal(size=3) * 0.3 + np.array([0., 1., 0.])
+            n /= np.linalg.norm(n)
+            lines.append(f"vn {n[0]:.4f} {n[1]:.4f} {n[2]:.4f}")
+    ref = (lambda i: f"{i}//{i}") if smooth else (lambda i: f"{i}")
+    faces = []
+    for iz in range(nz - 1):
+        for ix in range(nx - 1):
+            a = iz * nx + ix + 1
+            faces.append("f " + " ".join(ref(i) for i in (a, a + 1, a + nx + 1)))
+            faces.append("f " + " ".join(ref(i) for i in (a, a + nx + 1, a + nx)))
+    for k in range(len(faces)):
+        if rng.rand() < 0.15:
+            faces.append(faces[k])  # a repeated face
+    for _ in range(int(rng.randint(0, 4))):  # a polygon face fans over the WHOLE vertex list (F3), each time the same triangles
+        a = int(rng.randint(1, n_grid - nx - 2))
+        faces.insert(int(rng.randint(len(faces))), "f " + " ".join(ref(i) for i in (a, a + 1, a + nx + 1, a + nx)))
+    lines += faces
+    if n_loose:
+        lines.append("g loose")
+        for k in range(n_loose // 3):
+            a = n_grid + 3 * k + 1
+            lines.append("f " + " ".join(ref(i) for i in (a, a + 1, a + 2)))
+    return "\n".join(lines) + "\n", smooth
+
+
+def random_mesh_scene(seed, hsize=64, vsize=40):
+    """A seeded random world around one or two parsed meshes (BVH traversal, repeated triangles, mesh boxes, any-hit
+    shadows), optionally next to glass / mirror primitives and a floor."""
+    rng = np.random.RandomState(10_000 + seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    pick = lambda seq: seq[int(rng.randint(len(seq)))]
+    w = World()
+    for _ in range(int(rng.randint(1, 3))):
+        w.lights.append(Light.point_light((u(-10., 10.), u(5., 12.), u(-12., -3.)), (u(0.4, 1.), u(0.4, 1.), u(0.4, 1.))))
+    alone = False
+    for k in range(int(rng.randint(1, 3))):
+        text, smooth = random_mesh_obj(rng)
+        alone = alone or (smooth and rng.rand() < 0.5)
+        g, _ = rt.obj_to_group(text)
+        s = u(0.3, 0.9)
+        g.set_transform(translate(u(-2., 2.) + 5. * k, u(-0.5, 0.5), u(-2., 2.)) * rotate(u(-PI, PI), Axis.Y) *
+                        rotate(u(-0.4, 0.4), Axis.X) * scale(s, s * u(0.6, 1.6), s))
+        g.set_material(Material(color=(u(0., 1.), u(0., 1.), u(0., 1.)), diffuse=0.7, specular=u(0., 0.8), shininess=pick([20., 80., 200.]),
+                                reflective=pick([0., 0., 0.3]), transparency=pick([0., 0., 0., 0.5]), refractive_index=pick([1., 1.5])))
+        if rng.rand() < 0.3:
+            g.divide(int(rng.randint(2, 12)))
+        w.objects.append(g)
+    if not alone:  # smooth meshes next to other shapes make the reference panic (F5b): half of them stay alone
+        if rng.rand() < 0.7:
+            w.objects.append(Shape.plane().set_transform(translate(0., -1., 0.)).set_material(
+                Material(specular=0., reflective=pick([0., 0.2])).with_pattern(Pattern.checkered((0.8, 0.8, 0.8), (0.2, 0.2, 0.2)))))
+        for _ in range(int(rng.randint(0, 4))):
+            s = pick([Shape.sphere, Shape.cube, Shape.glass_sphere])()
+            r = u(0.5, 1.5)
+            s.set_transform(translate(u(-5., 8.), u(0.5, 3.), u(-4., 4.)) * scale(r, r, r))
+            s.set_material(pick([glass_material(), mirror_material(), Material(color=(u(0., 1.), u(0., 1.), u(0., 1.)))]))
+            w.objects.append(s)
+    cam = Camera(hsize, vsize, u(0.7, 1.3))
+    a = u(0., 2. * PI)
+    cam.transform = view_transform((2.5 + 12. * math.cos(a), u(2., 8.), 12. * math.sin(a)), (2.5 + u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
+    return w, cam
