@@ -72,6 +72,13 @@ __device__ __forceinline__ V3 xf_normal(M m, V3 v) {
 struct Work {
     unsigned xforms, box, gate, tri, tri_det, tri_u, tri_v, prim[5], bvh_nodes;
 };
+// A queue slot without a ray (tile padding, a refraction slot whose ray was totally internally reflected) is marked by
+// ONE particular NaN in its origin's x: a NaN with a payload no arithmetic produces.  An ordinary NaN there is a ray
+// like any other — the reference traces it (a plane only looks at y: it can even be hit) and so does this code.
+constexpr unsigned long long DEAD_RAY_BITS = 0x7ff8dead0000beefull;
+__device__ __forceinline__ double dead_ray() { return __longlong_as_double((long long)DEAD_RAY_BITS); }
+__device__ __forceinline__ bool is_dead_ray(double ox) { return (unsigned long long)__double_as_longlong(ox) == DEAD_RAY_BITS; }
+
 template <bool COUNT>
 __device__ __forceinline__ void bump(unsigned& c, unsigned n = 1) {
     if (COUNT) c += n;
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(CameraParams c, Level L, long 
     if (slot >= n_slots) return;
     int px, py;
     if (!slot_to_pixel(c, slot, px, py)) {
-        L.ox[slot] = NAN;  // padding slot: no ray
+        L.ox[slot] = dead_ray();  // padding slot: no ray
         return;
     }
     V3 origin, direction;
@@ -1293,7 +1300,7 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long lon
     // they overlap): a wavefront is one of four on its SIMD, so nothing else hides that round trip.
     auto fetch = [&](long long c, V3& o, V3& d) {
         const long long i = c * 64 + (threadIdx.x & 63);
-        o = mk(NAN, 0., 0.);  // NaN origin = padding slot / dead ray
+        o = mk(dead_ray(), 0., 0.);  // padding slot / dead ray
         d = mk(0., 0., 1.);
         if (c >= 0 && i < n) {
             o = mk(L.ox[i], L.oy[i], L.oz[i]);
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long lon
     fetch(c, o, d);
     while (c >= 0) {
         const long long i = c * 64 + (threadIdx.x & 63);
-        const bool alive = o.x == o.x;
+        const bool alive = !is_dead_ray(o.x);
         if (!alive) o = mk(0., 0., 0.);
         ClosestSink<NEED_FIRST> sink;
         sink.init(INFINITY);
@@ -1555,7 +1562,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
     }
     if (c1 >= 0) {
         if (stage & ST_TIR) {  // refracted_color returns BLACK (src/world.rs:128-130): the reserved slot is a dead ray
-            N.ox[c1] = NAN;
+            N.ox[c1] = dead_ray();
             L.child_refr[i] = -1;
         } else {  // refracted_color, src/world.rs:120-137
             double n_ratio = n1 / n2;

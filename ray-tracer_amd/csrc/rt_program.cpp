@@ -459,7 +459,16 @@ struct Compiler {
         const int32_t kind = d.node_kind[node];
         const double unit_lo[3] = {-1., -1., -1.}, unit_hi[3] = {1., 1., 1.};
         switch (kind) {
-            case RT_SPHERE: case RT_CUBE: return to_world(unit_lo, unit_hi, chain);
+            case RT_SPHERE: return to_world(unit_lo, unit_hi, chain);
+            case RT_CUBE: {
+                // never bounded: check_axis treats an object-space direction component below EPSILON as parallel
+                // (src/cube.rs:64-78), so that axis' slab is all of t when the ORIGIN lies between its planes, and the
+                // reference then reports hits whose points are |t| * EPSILON outside the cube — arbitrarily far for a
+                // distant origin.  Found by tests/test_gpu_fuzz.py (a cube scaled by 17 seen from 1e5 away).
+                WBox w;
+                w.bounded = false;
+                return w;
+            }
             case RT_PLANE: { WBox w; w.bounded = false; return w; }
             case RT_CONE: {
                 // never bounded: a ray parallel to the cone's side gets its single hit WITHOUT the minimum < y < maximum

@@ -14,8 +14,9 @@ seeds = [int(x) for x in sys.argv[1].split(",")]
 W, H = 64, 40
 for seed in seeds:
     mesh = len(sys.argv) > 2 and sys.argv[2] == "mesh"
-    depth = (3 if seed % 2 else 5) if mesh else (4 if seed % 3 else 6)
-    world, cam = (scenes.random_mesh_scene if mesh else scenes.random_scene)(seed, W, H)
+    wild = len(sys.argv) > 2 and sys.argv[2] == "wild"
+    depth = (3 if seed % 2 else 5) if mesh else 4 if wild else (4 if seed % 3 else 6)
+    world, cam = scenes.random_scene(seed, W, H, wild=True) if wild else (scenes.random_mesh_scene if mesh else scenes.random_scene)(seed, W, H)
     g = cam.render(world, depth)
     o = ob.render(world, cam, depth)
     line = [f"seed {seed} depth {depth} objects {len(world.objects)}"]

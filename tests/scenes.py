@@ -216,12 +216,14 @@ def cover_like_scene(hsize=200, vsize=200):
     return w, cam
 
 
-def random_scene(seed, hsize=64, vsize=40):
+def random_scene(seed, hsize=64, vsize=40, wild=False):
     """A seeded random world for the fuzz parity tests: every primitive kind, nested groups, CSG trees of every
     operation, small flat / smooth triangle fans, patterns with their own transforms, glass, mirrors, objects that
     cast no shadow, truncated and capped cylinders and cones, sheared transforms, one to three lights.  Transforms
-    keep |det| well above 1e-5 (F11: the reference panics on a non-invertible matrix)."""
-    rng = np.random.RandomState(seed)
+    keep |det| well above 1e-5 (F11: the reference panics on a non-invertible matrix).  `wild`: scales from 0.05 to
+    20, objects and camera ten times farther out, material parameters outside [0, 1], refractive indices of 0, -1
+    and infinity, lights inside the scene."""
+    rng = np.random.RandomState(seed + (500_000 if wild else 0))
     u = lambda lo, hi: float(rng.uniform(lo, hi))
     pick = lambda seq: seq[int(rng.randint(len(seq)))]
     colour = lambda: (u(0., 1.), u(0., 1.), u(0., 1.))
@@ -231,10 +233,11 @@ def random_scene(seed, hsize=64, vsize=40):
         m = m * rotate(u(-PI, PI), pick([Axis.X, Axis.Y, Axis.Z]))
         if rng.rand() < 0.25:
             m = m * rt.shear(u(-0.3, 0.3), 0., 0., u(-0.3, 0.3), 0., 0.)
+        lo, hi = (0.05, 20.) if wild and rng.rand() < 0.3 else (0.4, 1.6)
         if rng.rand() < 0.5:
-            s = u(0.4, 1.6)
+            s = u(lo, hi)
             return m * scale(s, s, s)
-        return m * scale(u(0.4, 1.6), u(0.4, 1.6), u(0.4, 1.6))
+        return m * scale(u(lo, hi), u(lo, hi), u(lo, hi))
 
     def pattern():
         kind = pick([Pattern.striped, Pattern.gradient, Pattern.ring, Pattern.checkered, Pattern.ring_gradient])
@@ -248,6 +251,9 @@ def random_scene(seed, hsize=64, vsize=40):
         m = Material(color=colour(), ambient=u(0., 0.3), diffuse=u(0.2, 0.9), specular=u(0., 1.),
                      shininess=pick([10., 50., 200., 300.]), reflective=pick([0., 0., 0.3, 1.]),
                      transparency=pick([0., 0., 0., 0.6, 1.]), refractive_index=pick([1., 1.3, 1.5, 2.417]))
+        if wild and rng.rand() < 0.4:
+            m = m.with_reflective(pick([1.5, -0.3, 1e-6, 0.999999])).with_transparency(pick([-0.2, 1.7, 1e-6, 0.5]))
+            m = m.with_refractive_index(pick([0., -1., float("inf"), 1e-3, 50.]))
         return m.with_pattern(pattern()) if rng.rand() < 0.4 else m
 
     def conic(shape):
@@ -302,14 +308,17 @@ def random_scene(seed, hsize=64, vsize=40):
     smooth_world = rng.rand() < 0.1  # a world of smooth fans only (next to other shapes the reference panics, F5b)
     for _ in range(int(rng.randint(3, 11))):
         s = fan(True) if smooth_world else compound(2)
-        s.set_transform(transform(4.))
+        s.set_transform(transform(40. if wild and rng.rand() < 0.3 else 4.))
         s.set_material(material())
         if rng.rand() < 0.15:
             s.set_casts_shadow(False)
         w.objects.append(s)
-    cam = Camera(hsize, vsize, u(0.6, 1.4))
+    if wild:
+        w.lights.append(Light.point_light((u(-2., 2.), u(0., 2.), u(-2., 2.)), (1., 1., 1.)))
+    cam = Camera(hsize, vsize, u(0.6, 1.4) if not wild else pick([0.05, 0.8, 2.8]))
     a = u(0., 2. * PI)
-    cam.transform = view_transform((11. * math.cos(a), u(1., 7.), 11. * math.sin(a)), (u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
+    r = 11. if not wild else pick([0.5, 11., 110.])
+    cam.transform = view_transform((r * math.cos(a), u(1., 7.), r * math.sin(a)), (u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
     return w, cam
 
 

@@ -37,6 +37,8 @@ def compare(seed, depth, builder=None):
     err[np.isnan(g.rgb) & np.isnan(o.rgb)] = 0.0
     err[np.isinf(g.rgb) & (g.rgb == o.rgb)] = 0.0
     err[over] = 0.0
+    # relative above 1: materials outside [0, 1] amplify colours to 1e7
+    err = err / np.maximum(1.0, np.nan_to_num(np.abs(o.rgb), nan=1.0, posinf=1.0))
     worst = float(np.nanmax(err)) if err.size else 0.0
     if not worst < COLOR_TOL or np.isnan(err).any():
         problems.append(f"colour error {worst:.3e} ({int((err >= COLOR_TOL).any(axis=-1).sum())} pixels, "
@@ -55,6 +57,16 @@ def test_random_worlds(first):
     failures = {}
     for seed in range(first, min(first + BATCH, N_SEEDS)):
         problems = compare(seed, depth=4 if seed % 3 else 6)
+        if problems:
+            failures[seed] = problems
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("first", range(0, N_SEEDS, BATCH))
+def test_random_wild_worlds(first):
+    failures = {}
+    for seed in range(first, min(first + BATCH, N_SEEDS)):
+        problems = compare(seed, depth=4, builder=lambda s, w, h: scenes.random_scene(s, w, h, wild=True))
         if problems:
             failures[seed] = problems
     assert not failures, failures
@@ -112,3 +124,52 @@ def test_random_lists_shadows_and_rays(first):
         if problems:
             failures[seed] = problems
     assert not failures, failures
+
+
+def _same_image(a, b, shift_ids=False):
+    ids_b = b.hit_id
+    if shift_ids and (a.hit_id > 0).any() and (b.hit_id > 0).any():  # object ids come from a process-wide counter
+        shift = int(b.hit_id[b.hit_id > 0].min()) - int(a.hit_id[a.hit_id > 0].min())
+        ids_b = np.where(b.hit_id > 0, b.hit_id - shift, 0)
+    return np.array_equal(a.rgb, b.rgb, equal_nan=True) and np.array_equal(a.hit_id, ids_b) and np.array_equal(a.flags, b.flags)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_worlds_on_every_render_path(seed, monkeypatch):
+    """One random world at a frame size that runs as two concurrent sub-frame chains: the level-by-level walk (with
+    rt_stats), the chained / graph-replayed path twice, a second camera on the same scene (new graph, queues that
+    may have to grow), three tile shards, and the scene rebuilt without cull ranges and with the GPU-built BVH all
+    give the same frame — and that frame matches the oracle on a sparse pixel sample."""
+    import math
+    builder = scenes.random_mesh_scene if seed % 2 else scenes.random_scene
+    size, depth, stride = (1100, 640), 4, 23
+    world, cam = builder(seed, *size)
+    a = cam.render(world, depth)
+    for _ in range(2):
+        assert _same_image(a, cam.render(world, depth, want_stats=False))
+    cam2 = rt.Camera(size[0], size[1], 0.9)
+    cam2.transform = rt.view_transform((9. * math.cos(seed), 4., 9. * math.sin(seed)), (0., 0.5, 0.), (0., 1., 0.))
+    b_fast = cam2.render(world, depth, want_stats=False)
+    assert _same_image(cam2.render(world, depth), b_fast)
+    assert _same_image(a, cam.render(world, depth, want_stats=False))  # back to the first view
+    acc, ids = np.zeros_like(a.rgb), np.zeros_like(a.hit_id)
+    for r in range(3):
+        s = cam.render(world, depth, rank=r, n_ranks=3, want_stats=False)
+        acc += np.nan_to_num(s.rgb, nan=-1e300)
+        ids += s.hit_id
+    assert np.array_equal(acc, np.nan_to_num(a.rgb, nan=-1e300)) and np.array_equal(ids, a.hit_id)
+    o = ob.render(world, cam, depth, stride=stride)
+    ys, xs = np.mgrid[0:size[1] - 1:stride, 0:size[0] - 1:stride]
+    over = (a.flags[ys, xs] & rt.RT_FLAG_LIST_OVERFLOW) != 0
+    assert over.mean() <= 0.01
+    assert np.array_equal(a.hit_id[ys, xs], o.hit_id[ys, xs])
+    assert np.array_equal(a.flags[ys, xs][~over], o.flags[ys, xs][~over])
+    err = np.abs(a.rgb[ys, xs] - o.rgb[ys, xs])
+    err[np.isnan(a.rgb[ys, xs]) & np.isnan(o.rgb[ys, xs])] = 0.
+    err[over] = 0.
+    assert not np.isnan(err).any() and float(err.max()) < COLOR_TOL
+    for name, value in (("RT_AMD_CULL", "0"), ("RT_AMD_DEVICE_BVH", "1")):
+        monkeypatch.setenv(name, value)
+        world2, cam_again = builder(seed, *size)
+        assert _same_image(a, cam_again.render(world2, depth, want_stats=False), shift_ids=True), name
+        monkeypatch.delenv(name)
