@@ -16,6 +16,33 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libraytracer_amd.so")  # RT_AMD_LIB: experiment builds
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; there is no fallback path")
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and ask for it by that file
+    name, which the loader does not match against an already loaded /opt/rocm/lib/libamdhip64.so.7 — so `import rt_amd`
+    followed by `import torch` put TWO runtimes into the process, and whichever of them touched the GPU second could
+    find no device.  If a torch with a bundled runtime is installed (not necessarily imported), its copy is loaded first
+    and this library binds to it by soname; without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is in the process already: the soname matches
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 EPSILON = 0.00001

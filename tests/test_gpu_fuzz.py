@@ -173,3 +173,21 @@ def test_random_worlds_on_every_render_path(seed, monkeypatch):
         world2, cam_again = builder(seed, *size)
         assert _same_image(a, cam_again.render(world2, depth, want_stats=False), shift_ids=True), name
         monkeypatch.delenv(name)
+
+
+def test_random_canvases_to_ppm():
+    """Canvas::canvas_to_ppm on the device against the host mirror, byte for byte: random widths around the 70-column
+    wrap, values far outside [0, 1], infinities, NaN, exact halves, denormals."""
+    import torch
+    world = rt.World.default()
+    rng = np.random.default_rng(77)
+    specials = np.array([np.inf, -np.inf, np.nan, 1e300, -1e300, 5e-324, -0., 0.5 / 255., 254.5 / 255., 1., 1. + 2e-16, 0.999999])
+    for _ in range(40):
+        shape = (int(rng.integers(1, 40)), int(rng.integers(1, 70)))
+        rgb = rng.uniform(-0.5, 1.5, size=shape + (3,))
+        mask = rng.uniform(size=rgb.shape) < 0.15
+        rgb[mask] = rng.choice(specials, size=int(mask.sum()))
+        t = torch.from_numpy(np.ascontiguousarray(rgb)).to("cuda:0")
+        torch.cuda.synchronize()
+        text = rt.canvas_to_ppm_device(world.scene(), t.data_ptr(), shape[1], shape[0])
+        assert text == rt.Image(rgb, None, None, None).to_ppm().encode(), shape
