@@ -402,3 +402,62 @@ def random_mesh_scene(seed, hsize=64, vsize=40):
     a = u(0., 2. * PI)
     cam.transform = view_transform((2.5 + 12. * math.cos(a), u(2., 8.), 12. * math.sin(a)), (2.5 + u(-1., 1.), u(0., 1.5), u(-1., 1.)), (0., 1., 0.))
     return w, cam
+
+
+def random_tie_scene(seed, hsize=64, vsize=40):
+    """Coincident surfaces on purpose: several shapes under the SAME transform (translations and power-of-two scales,
+    so the arithmetic is exact), CSG of shapes that share faces, a plane through a cube face.  Equal t values must come
+    out in the reference's order: stable sorts of the depth-first emission order (src/world.rs:46-55, group.rs:52-65)."""
+    rng = np.random.RandomState(900_000 + seed)
+    pick = lambda seq: seq[int(rng.randint(len(seq)))]
+    colour = lambda: (float(rng.uniform(0., 1.)), float(rng.uniform(0., 1.)), float(rng.uniform(0., 1.)))
+
+    def material():
+        return Material(color=colour(), reflective=pick([0., 0.4]), transparency=pick([0., 0., 0.7]), refractive_index=pick([1., 1.5]))
+
+    def shape():
+        k = int(rng.randint(4))
+        if k == 0:
+            return Shape.sphere()
+        if k == 1:
+            return Shape.cube()
+        if k == 2:
+            return Shape.cylinder().set_minimum(-1.).set_maximum(1.).set_closed(True)
+        return Shape.glass_sphere()
+
+    w = World()
+    w.lights.append(Light.point_light((-4., 8., -8.), rt.WHITE))
+    if rng.rand() < 0.5:
+        w.lights.append(Light.point_light((6., 6., -6.), (0.5, 0.5, 0.5)))
+    for cluster in range(int(rng.randint(1, 4))):
+        s = pick([0.5, 1., 2.])
+        base = translate(float(rng.randint(-3, 4)) * 2., float(rng.randint(0, 2)), float(rng.randint(-2, 3)) * 2.) * scale(s, s, s)
+        members = []
+        for _ in range(int(rng.randint(2, 5))):
+            r = rng.rand()
+            if r < 0.6:
+                m = shape()
+            elif r < 0.85:
+                m = Shape.csg(pick(["union", "intersection", "difference"]), shape(), shape())
+            else:
+                m = Shape.group()
+                for _ in range(2):
+                    m.add_child(shape())
+            m.set_material(material())
+            members.append(m)
+        if rng.rand() < 0.5:
+            g = Shape.group()
+            for m in members:
+                g.add_child(m)
+            g.set_transform(base)
+            w.objects.append(g)
+        else:
+            for m in members:
+                m.set_transform(base)
+                w.objects.append(m)
+        if rng.rand() < 0.5:  # a plane through the unit shapes' bottom face
+            w.objects.append(Shape.plane().set_transform(base * translate(0., -1., 0.)).set_material(material()))
+    cam = Camera(hsize, vsize, PI / 3.)
+    eye = pick([(0., 1., -12.), (0., 12., -3.), (-12., 1., 0.), (7., 5., -9.)])
+    cam.transform = view_transform(eye, (0., 0.5, 0.), (0., 1., 0.))
+    return w, cam

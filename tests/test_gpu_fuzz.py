@@ -73,6 +73,30 @@ def test_random_wild_worlds(first):
 
 
 @pytest.mark.parametrize("first", range(0, N_SEEDS, BATCH))
+def test_random_coincident_surfaces(first):
+    """Equal t values on purpose (shapes under one transform, shared faces): ids, colours, lists in the reference's order."""
+    failures = {}
+    for seed in range(first, min(first + BATCH, N_SEEDS)):
+        problems = compare(seed, depth=4, builder=scenes.random_tie_scene)
+        world, _ = scenes.random_tie_scene(seed, 16, 16)
+        rng = np.random.default_rng(seed)
+        n = 256
+        o = np.stack([rng.integers(-6, 7, size=n) * 1.0, rng.integers(-1, 4, size=n) * 0.5, np.full(n, -20.)], axis=1)
+        d = np.tile(np.array([0., 0., 1.]), (n, 1))
+        o[n // 2:] = o[n // 2:, [2, 1, 0]]   # the other half along +x
+        d[n // 2:] = (1., 0., 0.)
+        o[n // 2:, 0] = -20.
+        gc, gt, gi = world.intersect_world_batch(o, d, 64)
+        oc, ot, oi = ob.intersect_world_batch(world, o, d, 64)
+        same_t = (gt == ot) | (np.isnan(gt) & np.isnan(ot))
+        if not (np.array_equal(gc, oc) and same_t.all() and np.array_equal(gi, oi)):
+            problems.append(f"lists: {int((gc != oc).sum())} counts, {int((~same_t).sum())} t, {int((gi != oi).sum())} ids differ")
+        if problems:
+            failures[seed] = problems
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("first", range(0, N_SEEDS, BATCH))
 def test_random_meshes(first):
     failures = {}
     for seed in range(first, min(first + BATCH, N_SEEDS)):
