@@ -322,6 +322,19 @@ int rt_is_shadowed(rt_scene* scene, int64_t n_points, const double* points, uint
 int64_t rt_canvas_to_ppm(rt_scene* scene, const double* d_rgb_frame, int32_t hsize, int32_t vsize, uint8_t* d_quantised_out,
                          char* ppm_out, int64_t cap);
 
+/* rt_canvas_to_ppm for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc.  It calls no hipMalloc / hipFree / allocating
+ * routine: its only scratch (the per-row offsets of the text, vsize + 1 int64) lives in a file-scope device array of
+ * the library (128 KiB per GPU, held until the process ends), so vsize is limited to 16384 rows (RT_ERR_UNSUPPORTED
+ * beyond).  Every pointer is a DEVICE pointer owned by the caller: d_rgb_frame [vsize*hsize*3] f64 in,
+ * d_quantised_out [vsize*hsize*3] u8 out (REQUIRED here), d_ppm_out [cap] the whole PPM text, header included
+ * (nothing is written unless all of it fits), d_len_out nullable.  With d_len_out the text length is stored there in
+ * stream order, the call returns 0 without waiting and never blocks; without it the call waits for the stream and
+ * returns the length.  `stream` NULL = the scene's own stream.  All calls on one GPU share that GPU's scratch array:
+ * calls that overlap on one GPU (two streams, two threads) race — serialise them. */
+int64_t rt_canvas_to_ppm_noalloc(rt_scene* scene, const double* d_rgb_frame, int32_t hsize, int32_t vsize,
+                                 uint8_t* d_quantised_out, char* d_ppm_out, int64_t cap, int64_t* d_len_out, void* stream);
+
 /* Camera::ray_for_pixel (src/camera.rs:37-60) for a batch of pixels, evaluated by the device ray-generation
  * code on device 0: origins_out / directions_out [n][3] (host). */
 int rt_ray_for_pixel(const rt_camera_desc* camera, int64_t n, const int32_t* px, const int32_t* py, double* origins_out,

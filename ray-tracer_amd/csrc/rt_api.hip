@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,34 @@ extern "C" const char* rt_last_error(void) { return g_err; }
             return RT_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
+
+// ------------------------------------------------------------------------------------------------ static scratch
+// rt_canvas_to_ppm_noalloc (the one entry point that allocates nothing) keeps its only scratch — the per-row byte
+// counts / offsets of the PPM text, rows + 1 values — in this file-scope device array instead of a grown buffer.  Every
+// GPU the library runs on holds its own copy (128 KiB) until the process ends.  In host code the array's NAME is only a
+// stand-in for hipGetSymbolAddress: kernels get the per-device address looked up below, never the name.
+constexpr int NOALLOC_MAX_ROWS = 16384;
+static __device__ __align__(256) long long scratch[NOALLOC_MAX_ROWS + 1];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static long long* g_scratch_ptr[NOALLOC_MAX_DEVICES];  // [device] -> that device's copy of `scratch`, null until set up
+
+// Set-up, once per device, with that device current (rt_scene_create calls it: a scene is what every caller of the
+// entry point must hold, so the look-up — which may load the code object onto the device — never happens inside it).
+static int scratch_setup(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return RT_OK;  // such a device simply has no no-alloc entry point
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RT_OK;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = static_cast<long long*>(ptr);
+    return RT_OK;
+}
+static long long* scratch_of(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
+}
 
 // ------------------------------------------------------------------------------------------------ scene
 struct LevelStore {
@@ -661,6 +690,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     if (ndev <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { rt_set_error("device %d out of range (have %d)", device, ndev); return RT_ERR_NO_DEVICE; }
     HIP_TRY(hipSetDevice(device));
+    if ((rc = scratch_setup(device)) != RT_OK) return rc;
     rt_scene* s = new rt_scene();
     s->device = device;
     const rt_scene_desc& d = *desc;
@@ -956,12 +986,49 @@ int64_t rt_canvas_to_ppm(rt_scene* s, const double* d_rgb_frame, int32_t hsize, 
     const int64_t total = hl + body;
     if (!ppm_out || cap < total) return total;  // the length alone (call again with a buffer that holds it)
     if ((rc = grow(s->misc_c, size_t(body))) != RT_OK) return rc;
-    hipLaunchKernelGGL(k_ppm_write, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, q, vpr, (int)vsize, rows, static_cast<char*>(s->misc_c.p));
+    hipLaunchKernelGGL(k_ppm_write, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, q, vpr, (int)vsize, rows, static_cast<char*>(s->misc_c.p), -1ll);
     HIP_TRY(hipGetLastError());
     std::memcpy(ppm_out, header, size_t(hl));
     HIP_TRY(hipMemcpyAsync(ppm_out + hl, s->misc_c.p, size_t(body), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return total;
+}
+
+int64_t rt_canvas_to_ppm_noalloc(rt_scene* s, const double* d_rgb_frame, int32_t hsize, int32_t vsize, uint8_t* d_quantised_out,
+                                 char* d_ppm_out, int64_t cap, int64_t* d_len_out, void* stream) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!d_rgb_frame || !d_quantised_out || hsize < 1 || vsize < 1 || cap < 0 || (cap > 0 && !d_ppm_out)) {
+        rt_set_error("bad argument (the quantised frame is a required output here: it is this entry point's staging)");
+        return RT_ERR_BAD_ARG;
+    }
+    if (vsize > NOALLOC_MAX_ROWS) {
+        rt_set_error("rt_canvas_to_ppm_noalloc handles canvases of at most %d rows (got %d): its row-offset scratch is a fixed device array; "
+                     "use rt_canvas_to_ppm", NOALLOC_MAX_ROWS, vsize);
+        return RT_ERR_UNSUPPORTED;
+    }
+    long long* rows = scratch_of(s->device);  // this device's copy of `scratch` (never the array's name)
+    if (!rows) { rt_set_error("no static scratch on device %d", s->device); return RT_ERR_UNSUPPORTED; }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    const long long n = (long long)hsize * vsize * 3;
+    const int vpr = hsize * 3;
+    char header[64];
+    const int hl = std::snprintf(header, sizeof header, "P3\n%d %d\n255\n", hsize, vsize);
+    // Every word of rows[0 .. vsize] is rewritten by k_ppm_row_bytes / k_ppm_scan before anything reads it, so nothing
+    // of the previous call's contents has to be cleared; words past vsize are never read.
+    hipLaunchKernelGGL(k_quantise, dim3(blocks_for(n)), dim3(BLOCK), 0, st, d_rgb_frame, n, d_quantised_out);
+    hipLaunchKernelGGL(k_ppm_row_bytes, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, d_quantised_out, vpr, (int)vsize, rows);
+    hipLaunchKernelGGL(k_ppm_scan, dim3(1), dim3(BLOCK), 0, st, rows, (int)vsize);
+    hipLaunchKernelGGL(k_ppm_header, dim3(1), dim3(64), 0, st, (int)hsize, (int)vsize, rows, (int)vsize, d_ppm_out, (long long)cap,
+                       reinterpret_cast<long long*>(d_len_out));
+    if (cap > hl)
+        hipLaunchKernelGGL(k_ppm_write, dim3(blocks_for(vsize)), dim3(BLOCK), 0, st, d_quantised_out, vpr, (int)vsize, rows, d_ppm_out + hl,
+                           (long long)cap - hl);
+    HIP_TRY(hipGetLastError());
+    if (d_len_out) return 0;  // the length arrives in *d_len_out in stream order; no host wait here
+    long long body = 0;
+    HIP_TRY(hipMemcpyAsync(&body, rows + vsize, sizeof body, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return hl + body;
 }
 
 int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t remaining, double* rgb_out,

@@ -1755,10 +1755,15 @@ __global__ __launch_bounds__(BLOCK) void k_ppm_scan(long long* __restrict__ byte
 }
 
 // one thread per canvas row: the row's text at its offset
+// `body_cap` >= 0: the text buffer holds that many bytes; a body that does not fit is not written at all (the row
+// scan's total, offsets[rows], is already known on the device — the entry point that allocates nothing cannot ask the
+// host first).  < 0: the caller has sized the buffer from the total.
 __global__ __launch_bounds__(BLOCK) void k_ppm_write(const uint8_t* __restrict__ q, int values_per_row, int rows,
-                                                     const long long* __restrict__ offsets, char* __restrict__ text) {
+                                                     const long long* __restrict__ offsets, char* __restrict__ text,
+                                                     long long body_cap) {
     int r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= rows) return;
+    if (body_cap >= 0 && offsets[rows] > body_cap) return;
     const uint8_t* __restrict__ p = q + (size_t)r * values_per_row;
     char* out = text + offsets[r];
     int line = 0;  // characters in the current line, trailing space included (String::len in the reference)
@@ -1774,6 +1779,28 @@ __global__ __launch_bounds__(BLOCK) void k_ppm_write(const uint8_t* __restrict__
         line += nd + 1;
     }
     *out++ = '\n';
+}
+
+// The PPM header "P3\n{w} {h}\n255\n" written on the device (rt_canvas_to_ppm_noalloc: the whole text stays in HBM), and
+// the total length of the text for callers that read it in stream order.  One thread.
+__global__ void k_ppm_header(int hsize, int vsize, const long long* __restrict__ offsets, int rows, char* __restrict__ text,
+                             long long cap, long long* __restrict__ len_out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    char h[48];
+    int n = 0;
+    auto put_int = [&](int v) {
+        char d[12];
+        int k = 0;
+        do { d[k++] = char('0' + v % 10); v /= 10; } while (v > 0);
+        while (k > 0) h[n++] = d[--k];
+    };
+    h[n++] = 'P'; h[n++] = '3'; h[n++] = '\n';
+    put_int(hsize); h[n++] = ' '; put_int(vsize); h[n++] = '\n';
+    h[n++] = '2'; h[n++] = '5'; h[n++] = '5'; h[n++] = '\n';
+    const long long total = n + offsets[rows];
+    if (len_out) *len_out = total;
+    if (total <= cap)
+        for (int k = 0; k < n; ++k) text[k] = h[k];
 }
 
 // Kernel: load caller rays into level 0 (rt_color_at).

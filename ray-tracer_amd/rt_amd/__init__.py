@@ -131,7 +131,7 @@ class CMaterial(C.Structure):  # rth_material
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
                "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
-               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_last_error"]
+               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
                 "rth_triangle_new", "rth_smooth_triangle_new", "rth_csg_new", "rth_hexagon", "rth_shape_clone",
@@ -166,6 +166,9 @@ lib.rt_is_shadowed.argtypes = [C.c_void_p, C.c_int64, c_dp, c_bp]
 lib.rt_ray_for_pixel.argtypes = [C.POINTER(CameraDesc), C.c_int64, c_ip, c_ip, c_dp, c_dp]
 lib.rt_canvas_to_ppm.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64]
 lib.rt_canvas_to_ppm.restype = C.c_int64
+lib.rt_canvas_to_ppm_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p]
+lib.rt_canvas_to_ppm_noalloc.restype = C.c_int64
 
 for _n in ("rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform", "rth_matmul",
            "rth_material_default", "rth_shape_free", "rth_world_free"):
