@@ -8,8 +8,8 @@
  *
  * How it is pinned: the reference is Rust and there is no Rust toolchain in the build image (no rustc/cargo,
  * lazy_static not vendored), so the reference itself cannot be run here.  The restatement is pinned instead by
- * the reference's own unit-test vectors (tests/golden/reference_kats.json transcribes them; tests/test_oracle_kats.py
- * replays them, tolerance 1e-5 = the reference's near_eq).  Behaviours no reference test covers (last row/column
+ * the reference's own unit-test vectors (tests/golden/reference_kats.json holds them, transcribed by hand with
+ * file:line; tests/test_oracle_kats.py replays them, tolerance 1e-5 = the reference's near_eq).  Behaviours no reference test covers (last row/column
  * skipped, xs[0] u/v for smooth triangles, n1/n2 double match, nearest-hit-only shadows, infinite boxes of triangle
  * groups, stable-sort tie order) follow the cited source text literally.
  *
@@ -293,6 +293,18 @@ static int intersection_allowed(int op, int left_hit, int inside_left_hit, int i
     }
 }
 
+/* CSG::filter_intersections, src/csg.rs:106-126: xs is the sorted list of both operands' intersections */
+static void filter_intersections(const rt_scene_desc* d, int csg_node, const ilist* xs, ilist* out) {
+    int left = csg_node + 1;
+    int inside_left_hit = 0, inside_right_hit = 0;
+    int op = d->csg_op[d->node_param[csg_node]];
+    for (int i = 0; i < xs->n; ++i) {
+        int left_hit = node_in_subtree(d, left, xs->v[i].node);
+        if (intersection_allowed(op, left_hit, inside_left_hit, inside_right_hit)) il_push(out, xs->v[i]);
+        if (left_hit) inside_left_hit = !inside_left_hit; else inside_right_hit = !inside_right_hit;
+    }
+}
+
 static void intersect_node(const rt_scene_desc* d, int node, ray_t ray, ilist* out) {
     ray_t local_ray = ray_transform(ray, xf_inv(d, d->node_xform[node])); /* src/shape.rs:75-76 */
     switch (d->node_kind[node]) {
@@ -322,13 +334,7 @@ static void intersect_node(const rt_scene_desc* d, int node, ray_t ray, ilist* o
             intersect_node(d, left, local_ray, &xs);
             intersect_node(d, right, local_ray, &xs);
             il_sort(&xs);
-            int inside_left_hit = 0, inside_right_hit = 0; /* filter_intersections :106-126 */
-            int op = d->csg_op[d->node_param[node]];
-            for (int i = 0; i < xs.n; ++i) {
-                int left_hit = node_in_subtree(d, left, xs.v[i].node);
-                if (intersection_allowed(op, left_hit, inside_left_hit, inside_right_hit)) il_push(out, xs.v[i]);
-                if (left_hit) inside_left_hit = !inside_left_hit; else inside_right_hit = !inside_right_hit;
-            }
+            filter_intersections(d, node, &xs, out);
             il_free(&xs);
             break;
         }
@@ -822,6 +828,25 @@ int orc_bound_intersects(const double* box6, const double* origin, const double*
 }
 
 /* CSG::intersection_allowed (src/csg.rs:95-104) for the truth-table KAT. */
+/* CSG::filter_intersections on a literal, already sorted list (the reference's own test does exactly this,
+ * src/csg.rs:223-240): kept_index_out receives the indices that survive; returns how many. */
+int orc_filter_intersections(const rt_scene_desc* d, int csg_node, int n, const double* t, const int32_t* node, int32_t* kept_index_out) {
+    if (!d || csg_node < 0 || csg_node >= d->n_nodes || d->node_kind[csg_node] != RT_CSG) return -1;
+    ilist xs, out;
+    il_init(&xs);
+    il_init(&out);
+    for (int i = 0; i < n; ++i) {
+        isect x = {t[i], node[i], 0, (double)i, 0.}; /* u carries the original index */
+        il_push(&xs, x);
+    }
+    filter_intersections(d, csg_node, &xs, &out);
+    int m = out.n;
+    for (int i = 0; i < m; ++i) kept_index_out[i] = (int32_t)out.v[i].u;
+    il_free(&xs);
+    il_free(&out);
+    return m;
+}
+
 int orc_intersection_allowed(int op, int left_hit, int inside_left, int inside_right) {
     return intersection_allowed(op, left_hit, inside_left, inside_right);
 }

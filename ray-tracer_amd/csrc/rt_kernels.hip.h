@@ -667,7 +667,19 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                 int wr = s0;
                 for (int a = s0; a < cs->n; ++a) {
                     int node = (cs->key[a] & ~(1 << 30)) >> 2;
-                    bool left_hit = node >= it.a && node < it.b;  // Shape::includes by subtree membership
+                    // Shape::includes (src/shape.rs:422-435) is membership of the hit's object id among the left operand's
+                    // leaves: the node range of the left operand, plus the (normally empty) list of right-operand nodes
+                    // that carry an id of the left operand (a shape cloned into both operands keeps its id)
+                    bool left_hit = node >= it.a && node < it.b;
+                    if (it.chain_len > 0 && !left_hit) {
+                        const int* __restrict__ sh = S.chain_pool + it.chain;
+                        int lo_i = 0, hi_i = it.chain_len;  // binary search: the list ascends
+                        while (lo_i < hi_i) {
+                            const int mid = (lo_i + hi_i) >> 1;
+                            if (sh[mid] < node) lo_i = mid + 1; else hi_i = mid;
+                        }
+                        left_hit = lo_i < it.chain_len && sh[lo_i] == node;
+                    }
                     if (csg_allowed(it.op, left_hit, inl, inr)) {
                         cs->t[wr] = cs->t[a]; cs->u[wr] = cs->u[a]; cs->v[wr] = cs->v[a]; cs->key[wr] = cs->key[a];
                         ++wr;

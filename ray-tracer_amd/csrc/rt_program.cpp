@@ -662,6 +662,23 @@ struct Compiler {
         e.a = left;
         e.b = d.node_subtree_end[left];
         e.op = d.csg_op[d.node_param[node]];
+        {
+            // Shape::includes compares object ids (src/shape.rs:422-435), the device compares node ranges: the same thing
+            // unless one id sits in both operands (csg(op, s, s.clone()) keeps the id).  The right operand's leaves
+            // whose id also occurs in the left operand are listed (ascending) behind the item; normally there are none.
+            const int32_t end = d.node_subtree_end[node];
+            std::unordered_set<int32_t> left_ids;
+            for (int32_t i = left; i < right; ++i)
+                if (is_leaf_kind(d.node_kind[i])) left_ids.insert(d.node_object_id[i]);
+            std::vector<int32_t> shared;
+            for (int32_t i = right; i < end; ++i)
+                if (is_leaf_kind(d.node_kind[i]) && left_ids.count(d.node_object_id[i])) shared.push_back(i);
+            if (!shared.empty()) {
+                e.chain = int32_t(p.chain_pool.size());
+                e.chain_len = int32_t(shared.size());
+                p.chain_pool.insert(p.chain_pool.end(), shared.begin(), shared.end());
+            }
+        }
         p.items.push_back(e);
         p.has_csg = true;
     }
@@ -746,14 +763,6 @@ int validate(const rt_scene_desc& d, std::string& err) {
             if (left >= end) FAIL(RT_ERR_BAD_ARG, "node %d: CSG without operands", n);
             int32_t right = d.node_subtree_end[left];
             if (right <= left || right >= end || d.node_subtree_end[right] != end) FAIL(RT_ERR_BAD_ARG, "node %d: CSG needs exactly two operands", n);
-            // Shape::includes compares ids (src/shape.rs:422-435): the device tests node ranges instead, which is
-            // the same thing unless one id sits in both operands.
-            std::unordered_set<int32_t> left_ids;
-            for (int32_t i = left; i < right; ++i)
-                if (d.node_kind[i] <= RT_SMOOTH_TRIANGLE) left_ids.insert(d.node_object_id[i]);
-            for (int32_t i = right; i < end; ++i)
-                if (d.node_kind[i] <= RT_SMOOTH_TRIANGLE && left_ids.count(d.node_object_id[i]))
-                    FAIL(RT_ERR_UNSUPPORTED, "node %d: object id %d appears in both CSG operands", n, d.node_object_id[i]);
         }
     }
     return RT_OK;

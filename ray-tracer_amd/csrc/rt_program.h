@@ -19,7 +19,9 @@ enum ItemType : int32_t {
     ITEM_GATE = 1,       // reference Group gate: node = group node, a = group box index, skip = item after the subtree
     ITEM_MESH = 2,       // BVH over the triangle children of one group: a = BVH root node index
     ITEM_CSG_BEGIN = 3,  // open a CSG scratch segment: node = csg node
-    ITEM_CSG_END = 4,    // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op
+    ITEM_CSG_END = 4,    // sort + filter the segment: node = csg node, a..b = node range of the LEFT operand, op = csg op;
+                         // chain_len > 0: chain_pool[chain .. chain + chain_len) lists (ascending) the RIGHT operand's leaves
+                         // whose object id also occurs in the left operand — Shape::includes is by id (src/shape.rs:422-435)
     ITEM_CULL = 5        // acceleration only: padded WORLD-space bounds of everything up to item `skip` (a set of top-level
                          // objects); a ray that misses them, or meets them beyond what its sink still accepts, skips there.
                          // The six bounds overlay bytes 16..63 of the record (cull_box()).

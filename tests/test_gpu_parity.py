@@ -240,6 +240,58 @@ def test_color_at_and_shadows_for_random_rays(builder):
     assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
 
 
+def _shared_id_worlds():
+    """CSG trees whose operands share object ids: Shape::includes (src/shape.rs:422-435) compares ids, and a clone
+    keeps its id, so a hit on the RIGHT operand's copy counts as a left hit in filter_intersections (csg.rs:106-126)."""
+    glass = Material(color=(0.6, 0.8, 1.), diffuse=0.4, reflective=0.3, transparency=0.6, refractive_index=1.3)
+    red = Material(color=(0.9, 0.2, 0.2), reflective=0.2)
+    for op in ("union", "intersection", "difference", "nonsense"):
+        for variant in range(4):
+            w = World()
+            w.lights.append(Light.point_light((-6., 7., -8.), rt.WHITE))
+            w.objects.append(Shape.plane().set_transform(translate(0., -1.5, 0.)).set_material(Material(pattern=Pattern.checkered(rt.WHITE, rt.BLACK), reflective=0.1)))
+            s = Shape.sphere().set_material(glass if variant % 2 else red)
+            if variant == 0:      # csg(op, s, s.clone()): the very same surface twice
+                c = Shape.csg(op, s, s.clone())
+            elif variant == 1:    # the clone moved: same id, different surface
+                c = Shape.csg(op, s, s.clone().set_transform(translate(0.7, 0.2, 0.)))
+            elif variant == 2:    # the shared id deep inside: left = csg(difference, cube, s), right = group holding s's clone and a cone
+                cube = Shape.cube().set_transform(scale(0.8, 0.8, 0.8)).set_material(red)
+                g = Shape.group()
+                g.add_child(s.clone().set_transform(translate(-0.5, 0.4, 0.)))
+                g.add_child(Shape.cylinder().set_minimum(-1.).set_maximum(1.).set_closed(True).set_transform(translate(0.9, 0., 0.) * scale(0.4, 1., 0.4)))
+                c = Shape.csg(op, Shape.csg("difference", cube, s), g)
+            else:                 # a triangle fan cloned into both operands (a mesh on each side, every id shared)
+                fan, _ = rt.obj_to_group("\n".join(["v 0 1.2 0"] + ["v %.6f -0.8 %.6f" % (math.cos(k * PI / 5), math.sin(k * PI / 5)) for k in range(10)] +
+                                                    ["f 1 %d %d" % (2 + k, 2 + (k + 1) % 10) for k in range(10)]) + "\n")
+                fan.set_material(glass)
+                c = Shape.csg(op, fan, fan.clone().set_transform(translate(0.3, 0., 0.2)))
+            c.set_transform(translate(0., 0.2, 0.) * rotate(Axis.Y, 0.3))
+            w.objects.append(c)
+            yield op, variant, w
+
+
+def test_csg_operands_sharing_object_ids():  # VERDICT r1 item 7
+    cam = Camera(80, 60, PI / 3)
+    cam.transform = view_transform((0.5, 1.5, -5.), (0., 0., 0.), (0., 1., 0.))
+    o, d = _random_rays(1500, 9, center=(0., 0.2, 0.), radius=5.)
+    seen_filter_difference = False
+    for op, variant, w in _shared_id_worlds():
+        gc, gt, gi = w.intersect_world_batch(o, d, 64)
+        oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+        assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi), (op, variant)
+        assert_image_parity(w, cam)
+        g_rgb, g_id, g_fl = w.color_at_batch(o[:500], d[:500], 5)
+        o_rgb, o_id, o_fl = ob.color_at_batch(w, o[:500], d[:500], 5)
+        assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+        assert np.array_equal(w.is_shadowed_batch(o[:500]), ob.is_shadowed_batch(w, o[:500]))
+        if op == "union" and variant == 0:
+            # by ids every hit is a left hit: inside_right never toggles, so union keeps ALL four entries of a ray through
+            # the sphere (a node-range rule would drop the right operand's pair)
+            seen_filter_difference = bool((gc[(gc > 0)] >= 4).any())
+    assert seen_filter_difference
+
+
 def test_unbounded_cylinder_never_equal_to_itself():  # F14 end to end
     w = World()
     w.lights.append(Light.point_light((-5, 5, -5), rt.WHITE))

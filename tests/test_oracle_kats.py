@@ -1,8 +1,11 @@
 """Pins the oracle (oracle/rt_oracle.c) — and with it the host mirror + flattener it is fed by — to the reference's
-own unit-test vectors.  Every test names the reference test it transcribes
-(file:line under /root/reference/src).  Tolerance 1e-5 = the reference's near_eq / PartialEq for Tuple and Color.
-CPU only."""
+own unit-test vectors.  The vectors live in tests/golden/reference_kats.json (transcribed by hand
+from the reference's `#[cfg(test)]` modules, each table naming its file:line; scripts/make_reference_kats.py wrote the
+file); the tests below build the scenes the reference tests build and take inputs and expected values from there.
+Tolerance 1e-5 = the reference's near_eq / PartialEq for Tuple and Color.  CPU only."""
+import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +17,12 @@ from rt_amd import Axis, Camera, Light, Material, Pattern, Shape, World, rotate,
 PI = math.pi
 S2 = math.sqrt(2.)
 EPS = 1e-5
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as _f:
+    KAT = json.load(_f)
+
+
+def ray_of(r):
+    return (tuple(r[0]), tuple(r[1]))
 
 
 def near(a, b):
@@ -30,26 +39,28 @@ def world_of(*shapes, lights=None):
 
 # ------------------------------------------------------------------ camera.rs
 def test_pixel_size():  # camera.rs:108-127
-    assert abs(Camera(200, 125, PI / 2).pixel_size - 0.01) < EPS
-    assert abs(Camera(125, 200, PI / 2).pixel_size - 0.01) < EPS
+    for c in KAT["camera_pixel_size"]["cases"]:
+        assert abs(Camera(c["hsize"], c["vsize"], c["fov"]).pixel_size - c["pixel_size"]) < EPS
 
 
 def test_ray_for_pixel():  # camera.rs:130-161
-    cam = Camera(201, 101, PI / 2)
-    o, d = ob.rays_for_pixels(cam, [100, 0], [50, 0])
-    assert near(o[0], (0, 0, 0, 1)) and near(d[0], (0, 0, -1, 0))
-    assert near(d[1], (0.66519, 0.33259, -0.66851, 0))
-    cam.transform = rotate(PI / 4, Axis.Y) * translate(0., -2., 5.)
-    o, d = ob.rays_for_pixels(cam, [100], [50])
-    assert near(o[0], (0, 2, -5, 1)) and near(d[0], (S2 / 2, 0, -S2 / 2, 0))
+    k = KAT["camera_ray_for_pixel"]
+    for c in k["cases"]:
+        cam = Camera(k["hsize"], k["vsize"], k["fov"])
+        if c["transform"]:
+            assert c["transform"] == "rotate(PI/4, Y) * translate(0, -2, 5)"
+            cam.transform = rotate(PI / 4, Axis.Y) * translate(0., -2., 5.)
+        o, d = ob.rays_for_pixels(cam, [c["px"]], [c["py"]])
+        assert near(o[0], c["origin"] + [1]) and near(d[0], c["direction"] + [0])
 
 
 def test_render_default_world():  # camera.rs:164-178
+    k = KAT["camera_render_default_world"]
     w = World.default()
-    cam = Camera(11, 11, PI / 2)
-    cam.transform = view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0))
+    cam = Camera(k["hsize"], k["vsize"], k["fov"])
+    cam.transform = view_transform(k["from"], k["to"], k["up"])
     img = ob.render(w, cam)
-    assert near(img.pixel_at(5, 5), (0.38066, 0.47583, 0.2855))
+    assert near(img.pixel_at(*k["pixel"]), k["color"])
     # F1 (camera.rs:65-66): the last row and column are never written
     assert not img.rgb[10, :, :].any() and not img.rgb[:, 10, :].any()
 
@@ -57,67 +68,70 @@ def test_render_default_world():  # camera.rs:164-178
 # ------------------------------------------------------------------ world.rs
 def test_intersect_world():  # world.rs:186-203
     w = World.default()
-    xs = ob.intersect_world(w, ((0, 0, -5), (0, 0, 1)))
-    assert [t for t, _ in xs] == [4., 4.5, 5.5, 6.]
+    xs = ob.intersect_world(w, ray_of(KAT["world_intersect"]["ray"]))
+    assert [t for t, _ in xs] == KAT["world_intersect"]["t"]
 
 
 def test_shading_intersection():  # world.rs:206-218
+    k = KAT["world_shade_hit_outside"]
     w = World.default()
-    ray = ((0, 0, -5), (0, 0, 1))
-    _, c = ob.eval_list(w, ray, [(4., w.objects[0])], 0, ob.SHADE_HIT)
-    assert near(c, (0.38066, 0.47583, 0.2855))
+    _, c = ob.eval_list(w, ray_of(k["ray"]), [(k["t"], w.objects[k["object"]])], 0, ob.SHADE_HIT)
+    assert near(c, k["color"])
 
 
 def test_shading_from_inside():  # world.rs:221-234
+    k = KAT["world_shade_hit_inside"]
     w = World.default()
-    w.lights[0] = Light.point_light((0, 0.25, 0), rt.WHITE)
-    _, c = ob.eval_list(w, ((0, 0, 0), (0, 0, 1)), [(0.5, w.objects[1])], 0, ob.SHADE_HIT)
-    assert near(c, (0.90498, 0.90498, 0.90498))
+    w.lights[0] = Light.point_light(k["light"], rt.WHITE)
+    _, c = ob.eval_list(w, ray_of(k["ray"]), [(k["t"], w.objects[k["object"]])], 0, ob.SHADE_HIT)
+    assert near(c, k["color"])
 
 
 def test_color_at():  # world.rs:237-274
+    k = KAT["world_color_at"]
     w = World.default()
-    assert near(ob.color_at(w, ((0, 0, -5), (0, 1, 0))), (0, 0, 0))
-    assert near(ob.color_at(w, ((0, 0, -5), (0, 0, 1))), (0.38066, 0.47583, 0.2855))
+    assert near(ob.color_at(w, ray_of(k["miss_ray"])), k["miss"])
+    assert near(ob.color_at(w, ray_of(k["hit_ray"])), k["hit"])
     w2 = World.default()
     for o in w2.objects:
         m = o.get_material()
         m.ambient = 1.
         o.set_material(m)
     inner = w2.objects[1].get_material().color
-    assert near(ob.color_at(w2, ((0, 0, 0.75), (0, 0, -1))), inner)
+    assert near(ob.color_at(w2, ray_of(k["behind_ray"])), inner)
 
 
 def test_is_shadowed():  # world.rs:277-306
     w = World.default()
-    assert ob.is_shadowed(w, (0, 10, 0)) == [False]
-    assert ob.is_shadowed(w, (10, -10, 10)) == [True]
-    assert ob.is_shadowed(w, (-20, 20, -20)) == [False]
-    assert ob.is_shadowed(w, (-2, 2, -2)) == [False]
+    for c in KAT["world_is_shadowed"]["cases"]:
+        assert ob.is_shadowed(w, c["point"]) == [c["shadowed"]]
 
 
 def test_shade_hit_in_shadow():  # world.rs:309-326
+    k = KAT["world_shade_hit_in_shadow"]
     s1 = Shape.sphere()
-    s2 = Shape.sphere().set_transform(translate(0, 0, 10))
-    w = world_of(s1, s2, lights=[Light.point_light((0, 0, -10), rt.WHITE)])
-    _, c = ob.eval_list(w, ((0, 0, 5), (0, 0, 1)), [(4., s2)], 0, ob.SHADE_HIT)
-    assert near(c, (0.1, 0.1, 0.1))
+    s2 = Shape.sphere().set_transform(translate(*k["s2_translate"]))
+    w = world_of(s1, s2, lights=[Light.point_light(k["light"], rt.WHITE)])
+    _, c = ob.eval_list(w, ray_of(k["ray"]), [(k["t"], s2)], 0, ob.SHADE_HIT)
+    assert near(c, k["color"])
 
 
 def test_no_shadow_when_not_casting():  # world.rs:575-588 (F8)
-    sphere = Shape.sphere().set_transform(translate(0, 3, 0)).set_casts_shadow(False)
-    w = world_of(sphere, Shape.plane(), lights=[Light.point_light((0, 10, 0), rt.WHITE)])
-    assert ob.is_shadowed(w, (0, 0, 0)) == [False]
+    k = KAT["world_no_shadow_when_not_casting"]
+    sphere = Shape.sphere().set_transform(translate(*k["sphere_translate"])).set_casts_shadow(False)
+    w = world_of(sphere, Shape.plane(), lights=[Light.point_light(k["light"], rt.WHITE)])
+    assert ob.is_shadowed(w, k["point"]) == [k["shadowed"]]
 
 
 def reflective_plane_world(**mat):
     w = World.default()
-    plane = Shape.plane().set_material(Material(**mat)).set_transform(translate(0, -1, 0))
+    plane = Shape.plane().set_material(Material(**mat)).set_transform(translate(*KAT["world_reflection"]["plane_translate"]))
     w.objects.append(plane)
     return w, plane
 
 
-RAY45 = ((0, 0, -3), (0, -S2 / 2, S2 / 2))
+RAY45 = ray_of(KAT["world_reflection"]["ray45"])
+T45 = KAT["world_reflection"]["t"]
 
 
 def test_reflected_color():  # world.rs:329-364, 412-429
@@ -127,18 +141,19 @@ def test_reflected_color():  # world.rs:329-364, 412-429
     m.ambient = 1.
     shape.set_material(m)
     _, c = ob.eval_list(w, ((0, 0, 0), (0, 0, 1)), [(1., shape)], 0, ob.REFLECTED)
-    assert near(c, (0, 0, 0))
-    w, plane = reflective_plane_world(reflective=0.5)
-    _, c = ob.eval_list(w, RAY45, [(S2, plane)], 0, ob.REFLECTED)
-    assert near(c, (0.19033, 0.23791, 0.14274))
-    _, c = ob.eval_list(w, RAY45, [(S2, plane)], 0, ob.REFLECTED, remaining=0)
-    assert near(c, (0, 0, 0))
+    k = KAT["world_reflection"]
+    assert near(c, k["nonreflective"])
+    w, plane = reflective_plane_world(reflective=k["reflective"])
+    _, c = ob.eval_list(w, RAY45, [(T45, plane)], 0, ob.REFLECTED)
+    assert near(c, k["reflected"])
+    _, c = ob.eval_list(w, RAY45, [(T45, plane)], 0, ob.REFLECTED, remaining=0)
+    assert near(c, k["at_max_depth"])
 
 
 def test_shade_hit_reflective():  # world.rs:367-384
-    w, plane = reflective_plane_world(reflective=0.5)
-    _, c = ob.eval_list(w, RAY45, [(S2, plane)], 0, ob.SHADE_HIT)
-    assert near(c, (0.87675, 0.92434, 0.82917))
+    w, plane = reflective_plane_world(reflective=KAT["world_reflection"]["reflective"])
+    _, c = ob.eval_list(w, RAY45, [(T45, plane)], 0, ob.SHADE_HIT)
+    assert near(c, KAT["world_reflection"]["shade_hit"])
 
 
 def test_mutually_reflective_surfaces_terminate():  # world.rs:387-409
@@ -154,14 +169,15 @@ def test_refracted_color_cases():  # world.rs:432-485
     shape = w.objects[0]
     ray = ((0, 0, -5), (0, 0, 1))
     _, c = ob.eval_list(w, ray, [(4., shape), (6., shape)], 0, ob.REFRACTED, remaining=5)
-    assert near(c, (0, 0, 0))  # opaque
+    k = KAT["world_refraction"]
+    assert near(c, k["opaque"])
     w = World.default()
     w.objects[0].set_material(Material(color=(0.8, 1., 0.6), diffuse=0.7, specular=0.2, transparency=1., refractive_index=1.5))
     shape = w.objects[0]
     _, c = ob.eval_list(w, ray, [(4., shape), (6., shape)], 0, ob.REFRACTED, remaining=0)
-    assert near(c, (0, 0, 0))  # max depth
-    _, c = ob.eval_list(w, ((0, 0, S2 / 2), (0, 1, 0)), [(-S2 / 2, shape), (S2 / 2, shape)], 1, ob.REFRACTED)
-    assert near(c, (0, 0, 0))  # total internal reflection
+    assert near(c, k["max_depth"])
+    _, c = ob.eval_list(w, ray_of(k["tir_ray"]), [(t, shape) for t in k["tir_xs"]], 1, ob.REFRACTED)
+    assert near(c, k["total_internal_reflection"])
 
 
 def test_refracted_color_with_refracted_ray():  # world.rs:488-511
@@ -169,9 +185,10 @@ def test_refracted_color_with_refracted_ray():  # world.rs:488-511
     w.objects[0].set_material(Material(ambient=1.).with_pattern(Pattern.test()))
     w.objects[1].set_material(Material(transparency=1., refractive_index=1.5))
     a, b = w.objects
-    xs = [(-0.9899, a), (-0.4899, b), (0.4899, b), (0.9899, a)]
-    _, c = ob.eval_list(w, ((0, 0, 0.1), (0, 1, 0)), xs, 2, ob.REFRACTED)
-    assert near(c, (0, 0.99887, 0.04722))
+    k = KAT["world_refraction"]
+    xs = list(zip(k["refracted_xs"], (a, b, b, a)))
+    _, c = ob.eval_list(w, ray_of(k["refracted_ray"]), xs, 2, ob.REFRACTED)
+    assert near(c, k["refracted"])
 
 
 def floor_ball_world(**floor_mat):
@@ -184,27 +201,29 @@ def floor_ball_world(**floor_mat):
 
 def test_shade_hit_transparent():  # world.rs:514-541
     w, floor = floor_ball_world(transparency=0.5, refractive_index=1.5)
-    _, c = ob.eval_list(w, RAY45, [(S2, floor)], 0, ob.SHADE_HIT)
-    assert near(c, (0.93642, 0.68642, 0.68642))
+    _, c = ob.eval_list(w, RAY45, [(T45, floor)], 0, ob.SHADE_HIT)
+    assert near(c, KAT["world_refraction"]["transparent_floor"])
     # the same through color_at on the real intersection list
-    assert near(ob.color_at(w, RAY45), (0.93642, 0.68642, 0.68642))
+    assert near(ob.color_at(w, RAY45), KAT["world_refraction"]["transparent_floor"])
 
 
 def test_shade_hit_reflective_transparent_schlick():  # world.rs:544-572
     w, floor = floor_ball_world(reflective=0.5, transparency=0.5, refractive_index=1.5)
-    _, c = ob.eval_list(w, RAY45, [(S2, floor)], 0, ob.SHADE_HIT)
-    assert near(c, (0.93391, 0.69643, 0.69243))
+    _, c = ob.eval_list(w, RAY45, [(T45, floor)], 0, ob.SHADE_HIT)
+    assert near(c, KAT["world_refraction"]["schlick_floor"])
 
 
 # ------------------------------------------------------------------ intersection.rs
 def test_prepare_computations_outside_inside():  # intersection.rs:235-294
     s = Shape.sphere()
     w = world_of(s)
-    c, _ = ob.eval_list(w, ((0, 0, -5), (0, 0, 1)), [(4., s)], 0)
-    assert c.t == 4. and near(c.point, (0, 0, -1)) and near(c.eye_vector, (0, 0, -1)) and near(c.normal_vector, (0, 0, -1))
-    assert not c.inside and c.n1 == 1. and c.n2 == 1.
-    c, _ = ob.eval_list(w, ((0, 0, 0), (0, 0, 1)), [(1., s)], 0)
-    assert near(c.point, (0, 0, 1)) and near(c.eye_vector, (0, 0, -1)) and near(c.normal_vector, (0, 0, -1)) and c.inside
+    for which in ("outside", "inside"):
+        k = KAT["prepare_computations"][which]
+        c, _ = ob.eval_list(w, ray_of(k["ray"]), [(k["t"], s)], 0)
+        assert c.t == k["t"] and near(c.point, k["point"]) and near(c.eye_vector, k["eye"]) and near(c.normal_vector, k["normal"])
+        assert c.inside == k["inside"]
+        if which == "outside":
+            assert c.n1 == 1. and c.n2 == 1.
 
 
 def test_over_and_under_point():  # intersection.rs:297-306, 356-366
@@ -216,48 +235,48 @@ def test_over_and_under_point():  # intersection.rs:297-306, 356-366
 
 def test_reflect_vector():  # intersection.rs:309-320
     p = Shape.plane()
-    c, _ = ob.eval_list(world_of(p), ((0, 1, -1), (0, -S2 / 2, S2 / 2)), [(S2, p)], 0)
-    assert near(c.reflect_vector, (0, S2 / 2, S2 / 2))
+    k = KAT["prepare_computations"]["reflect"]
+    c, _ = ob.eval_list(world_of(p), ray_of(k["ray"]), [(k["t"], p)], 0)
+    assert near(c.reflect_vector, k["reflect"])
 
 
 def test_n1_n2():  # intersection.rs:323-353
+    k = KAT["n1_n2"]
     a = Shape.glass_sphere().set_transform(scale(2, 2, 2))
-    b = Shape.glass_sphere().set_transform(translate(0, 0, -0.25)).set_material(Material(refractive_index=2.))
-    c_ = Shape.glass_sphere().set_transform(scale(2, 2, 2)).set_material(Material(refractive_index=2.5))
+    b = Shape.glass_sphere().set_transform(translate(0, 0, -0.25)).set_material(Material(refractive_index=k["indices"]["b"]))
+    c_ = Shape.glass_sphere().set_transform(scale(2, 2, 2)).set_material(Material(refractive_index=k["indices"]["c"]))
     # NB: the reference test gives b and c default materials with only refractive_index changed
+    assert a.get_material().refractive_index == k["indices"]["a"]
     w = world_of(a, b, c_)
-    xs = [(2., a), (2.75, b), (3.25, c_), (4.75, b), (5.25, c_), (6., a)]
-    expected = [(1., 1.5), (1.5, 2.), (2., 2.5), (2.5, 2.5), (2.5, 1.5), (1.5, 1.)]
-    for i, (n1, n2) in enumerate(expected):
-        c, _ = ob.eval_list(w, ((0, 0, -4), (0, 0, -1)), xs, i)
+    by_name = {"a": a, "b": b, "c": c_}
+    xs = [(t, by_name[n]) for t, n in k["xs"]]
+    for i, (n1, n2) in enumerate(k["expected"]):
+        c, _ = ob.eval_list(w, ray_of(k["ray"]), xs, i)
         assert abs(c.n1 - n1) < EPS and abs(c.n2 - n2) < EPS
 
 
 def test_schlick():  # intersection.rs:369-410
     s = Shape.glass_sphere()
     w = world_of(s)
-    _, r = ob.eval_list(w, ((0, 0, S2), (0, 1, 0)), [(-S2 / 2, s), (S2 / 2, s)], 1, ob.SCHLICK)
-    assert abs(r - 1.) < EPS
-    _, r = ob.eval_list(w, ((0, 0, 0), (0, 1, 0)), [(-1., s), (1., s)], 1, ob.SCHLICK)
-    assert abs(r - 0.04) < EPS
-    _, r = ob.eval_list(w, ((0, 0.99, -2), (0, 0, 1)), [(1.8589, s)], 0, ob.SCHLICK)
-    assert abs(r - 0.48873) < EPS
+    for c in KAT["schlick"]["cases"]:
+        _, r = ob.eval_list(w, ray_of(c["ray"]), [(t, s) for t in c["xs"]], c["hit"], ob.SCHLICK)
+        assert abs(r - c["reflectance"]) < EPS
 
 
 # ------------------------------------------------------------------ primitives
 def test_sphere_intersections():  # sphere.rs:107-196
     s = Shape.sphere()
     w = world_of(s)
-    cases = [((0, 0, -5), (4., 6.)), ((0, 1, -5), (5., 5.)), ((0, 0, 0), (-1., 1.)), ((0, 0, 5), (-6., -4.))]
-    for o, ts in cases:
-        t, _ = ob.local_intersect(w, s, o, (0, 0, 1))
-        assert near(t, ts)
-    assert ob.local_intersect(w, s, (0, 2, -5), (0, 0, 1))[0] == []
+    k = KAT["sphere"]
+    for c in k["hits"]:
+        t, _ = ob.local_intersect(w, s, c["origin"], k["direction"])
+        assert near(t, c["t"])
+    assert ob.local_intersect(w, s, k["miss_origin"], k["direction"])[0] == []
 
 
 def test_sphere_scaled_translated():  # sphere.rs (intersecting scaled / translated sphere)
     s = Shape.sphere().set_transform(scale(2, 2, 2))
-    assert near([t for t, _ in ob.intersect_world(world_of(s), ((0, 0, -5), (0, 0, 1)))], (3., 7.))
+    assert near([t for t, _ in ob.intersect_world(world_of(s), ((0, 0, -5), (0, 0, 1)))], KAT["sphere"]["scaled2_t"])
     s = Shape.sphere().set_transform(translate(5, 0, 0))
     assert ob.intersect_world(world_of(s), ((0, 0, -5), (0, 0, 1))) == []
 
@@ -265,28 +284,23 @@ def test_sphere_scaled_translated():  # sphere.rs (intersecting scaled / transla
 def test_plane():  # plane.rs:93-144
     p = Shape.plane()
     w = world_of(p)
-    assert ob.local_intersect(w, p, (0, 10, 0), (0, 0, 1))[0] == []
-    assert ob.local_intersect(w, p, (0, 0, 0), (0, 0, 1))[0] == []
-    assert near(ob.local_intersect(w, p, (0, 1, 0), (0, -1, 0))[0], [1.])
-    assert near(ob.local_intersect(w, p, (0, -1, 0), (0, 1, 0))[0], [1.])
-    assert near(ob.local_normal_at(w, p, (10, 0, -10)), (0, 1, 0))
+    k = KAT["plane"]
+    for o, d in k["misses"]:
+        assert ob.local_intersect(w, p, o, d)[0] == []
+    for c in k["hits"]:
+        assert near(ob.local_intersect(w, p, *c["ray"])[0], [c["t"]])
+    assert near(ob.local_normal_at(w, p, k["normal_at"][0]), k["normal_at"][1])
 
 
 def test_cube():  # cube.rs:108-185
     c = Shape.cube()
     w = world_of(c)
-    hits = [((5, 0.5, 0), (-1, 0, 0), (4, 6)), ((-5, 0.5, 0), (1, 0, 0), (4, 6)), ((0.5, 5, 0), (0, -1, 0), (4, 6)),
-            ((0.5, -5, 0), (0, 1, 0), (4, 6)), ((0.5, 0, 5), (0, 0, -1), (4, 6)), ((0.5, 0, -5), (0, 0, 1), (4, 6)),
-            ((0, 0.5, 0), (0, 0, 1), (-1, 1))]
-    for o, d, ts in hits:
+    k = KAT["cube"]
+    for o, d, ts in k["hits"]:
         assert near(ob.local_intersect(w, c, o, d)[0], ts)
-    misses = [((-2, 0, 0), (0.2673, 0.5345, 0.8018)), ((0, -2, 0), (0.8018, 0.2673, 0.5345)),
-              ((0, 0, -2), (0.5345, 0.8018, 0.2673)), ((2, 0, 2), (0, 0, -1)), ((0, 2, 2), (0, -1, 0)), ((2, 2, 0), (-1, 0, 0))]
-    for o, d in misses:
+    for o, d in k["misses"]:
         assert ob.local_intersect(w, c, o, d)[0] == []
-    normals = [((1, 0.5, -0.8), (1, 0, 0)), ((-1, -0.2, 0.9), (-1, 0, 0)), ((-0.4, 1, -0.1), (0, 1, 0)),
-               ((0.3, -1, -0.7), (0, -1, 0)), ((-0.6, 0.3, 1), (0, 0, 1)), ((0.4, 0.4, -1), (0, 0, -1)),
-               ((1, 1, 1), (1, 0, 0)), ((-1, -1, -1), (-1, 0, 0))]
+    normals = k["normals"]
     for p, n in normals:
         assert near(ob.local_normal_at(w, c, p), n)
 
@@ -299,69 +313,68 @@ def norm(v):
 def test_cylinder():  # cylinder.rs:145-311
     cyl = Shape.cylinder()
     w = world_of(cyl)
-    for o, d in [((1, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 1, 0)), ((0, 0, -5), (1, 1, 1))]:
+    k = KAT["cylinder"]
+    for o, d in k["misses"]:
         assert ob.local_intersect(w, cyl, o, norm(d))[0] == []
-    for o, d, ts in [((1, 0, -5), (0, 0, 1), (5, 5)), ((0, 0, -5), (0, 0, 1), (4, 6)), ((0.5, 0, -5), (0.1, 1, 1), (6.80798, 7.08872))]:
+    for o, d, ts in k["hits"]:
         assert near(ob.local_intersect(w, cyl, o, norm(d))[0], ts)
-    for p, n in [((1, 0, 0), (1, 0, 0)), ((0, 5, -1), (0, 0, -1)), ((0, -2, 1), (0, 0, 1)), ((-1, 1, 0), (-1, 0, 0))]:
+    for p, n in k["normals"]:
         assert near(ob.local_normal_at(w, cyl, p), n)
-    trunc = Shape.cylinder().set_minimum(1.).set_maximum(2.)
+    tr = k["truncated"]
+    trunc = Shape.cylinder().set_minimum(tr["minimum"]).set_maximum(tr["maximum"])
     w = world_of(trunc)
-    rays = [((0, 1.5, 0), (0.1, 1, 0)), ((0, 3, -5), (0, 0, 1)), ((0, 0, -5), (0, 0, 1)), ((0, 2, -5), (0, 0, 1)),
-            ((0, 1, -5), (0, 0, 1)), ((0, 1.5, -2), (0, 0, 1))]
-    assert [len(ob.local_intersect(w, trunc, o, norm(d))[0]) for o, d in rays] == [0, 0, 0, 0, 0, 2]
-    capped = Shape.cylinder().set_minimum(1.).set_maximum(2.).set_closed(True)
+    assert [len(ob.local_intersect(w, trunc, o, norm(d))[0]) for o, d in tr["rays"]] == tr["counts"]
+    cp = k["capped"]
+    capped = Shape.cylinder().set_minimum(cp["minimum"]).set_maximum(cp["maximum"]).set_closed(True)
     w = world_of(capped)
-    rays = [((0, 3, 0), (0, -1, 0)), ((0, 3, -2), (0, -1, 2)), ((0, 4, -2), (0, -1, 1)), ((0, 0, -2), (0, 1, 2)), ((0, -1, -2), (0, 1, 1))]
-    assert [len(ob.local_intersect(w, capped, o, norm(d))[0]) for o, d in rays] == [2] * 5
-    caps = [((0, 1, 0), (0, -1, 0)), ((0.5, 1, 0), (0, -1, 0)), ((0, 1, 0.5), (0, -1, 0)), ((0, 2, 0), (0, 1, 0)),
-            ((0.5, 2, 0), (0, 1, 0)), ((0, 2, 0.5), (0, 1, 0))]
-    for p, n in caps:
+    assert [len(ob.local_intersect(w, capped, o, norm(d))[0]) for o, d in cp["rays"]] == cp["counts"]
+    for p, n in cp["cap_normals"]:
         assert near(ob.local_normal_at(w, capped, p), n)
 
 
 def test_cone():  # cone.rs:156-236
     cone = Shape.cone()
     w = world_of(cone)
-    for o, d, ts in [((0, 0, -5), (0, 0, 1), (5, 5)), ((0, 0, -5), (1, 1, 1), (8.66025, 8.66025)),
-                     ((1, 1, -5), (-0.5, -1, 1), (4.55006, 49.44994))]:
+    k = KAT["cone"]
+    for o, d, ts in k["hits"]:
         assert near(ob.local_intersect(w, cone, o, norm(d))[0], ts)
-    t, _ = ob.local_intersect(w, cone, (0, 0, -1), norm((0, 1, 1)))
-    assert len(t) == 1 and abs(t[0] - 0.35355) < EPS
-    capped = Shape.cone().set_minimum(-0.5).set_maximum(0.5).set_closed(True)
+    t, _ = ob.local_intersect(w, cone, k["parallel_to_half"]["ray"][0], norm(k["parallel_to_half"]["ray"][1]))
+    assert len(t) == 1 and abs(t[0] - k["parallel_to_half"]["t"]) < EPS
+    cp = k["capped"]
+    capped = Shape.cone().set_minimum(cp["minimum"]).set_maximum(cp["maximum"]).set_closed(True)
     w2 = world_of(capped)
-    rays = [((0, 0, -5), (0, 1, 0)), ((0, 0, -0.25), (0, 1, 1)), ((0, 0, -0.25), (0, 1, 0))]
-    assert [len(ob.local_intersect(w2, capped, o, norm(d))[0]) for o, d in rays] == [0, 2, 4]
-    for p, n in [((0, 0, 0), (0, 0, 0)), ((1, 1, 1), (1, -S2, 1)), ((-1, -1, 0), (-1, 1, 0))]:
+    assert [len(ob.local_intersect(w2, capped, o, norm(d))[0]) for o, d in cp["rays"]] == cp["counts"]
+    for p, n in k["normals"]:
         assert near(ob.local_normal_at(w, cone, p), n)
 
 
 def test_triangle():  # triangle.rs:105-195
-    t = Shape.triangle((0, 1, 0), (-1, 0, 0), (1, 0, 0))
+    k = KAT["triangle"]
+    t = Shape.triangle(*k["points"])
     data = t.triangle_data()
-    assert near(data[3], (-1, -1, 0)) and near(data[4], (1, -1, 0)) and near(data[5], (0, 0, -1))
+    assert near(data[3], k["e1"]) and near(data[4], k["e2"]) and near(data[5], k["normal"])
     w = world_of(t)
-    for p in [(0, 0.5, 0), (-0.5, 0.75, 0), (0.5, 0.25, 0)]:
-        assert near(ob.local_normal_at(w, t, p), (0, 0, -1))
-    assert ob.local_intersect(w, t, (0, -1, -2), (0, 1, 0))[0] == []   # parallel
-    assert ob.local_intersect(w, t, (1, 1, -2), (0, 0, 1))[0] == []    # p1-p3 edge
-    assert ob.local_intersect(w, t, (-1, 1, -2), (0, 0, 1))[0] == []   # p1-p2 edge
-    assert ob.local_intersect(w, t, (0, -1, -2), (0, 0, 1))[0] == []   # p2-p3 edge
-    assert near(ob.local_intersect(w, t, (0, 0.5, -2), (0, 0, 1))[0], [2.])
+    for p in k["normal_points"]:
+        assert near(ob.local_normal_at(w, t, p), k["normal"])
+    for o, d in k["misses"]:   # parallel, p1-p3 edge, p1-p2 edge, p2-p3 edge
+        assert ob.local_intersect(w, t, o, d)[0] == []
+    assert near(ob.local_intersect(w, t, *k["hit"]["ray"])[0], [k["hit"]["t"]])
 
 
 def smooth_tri():
-    return Shape.smooth_triangle((0, 1, 0), (-1, 0, 0), (1, 0, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0))
+    k = KAT["smooth_triangle"]
+    return Shape.smooth_triangle(*(k["points"] + k["normals"]))
 
 
 def test_smooth_triangle():  # smooth_triangle.rs:151-196
     t = smooth_tri()
     w = world_of(t)
-    ts, uv = ob.local_intersect(w, t, (-0.2, 0.3, -2), (0, 0, 1))
-    assert len(ts) == 1 and abs(uv[0][0] - 0.45) < EPS and abs(uv[0][1] - 0.25) < EPS
-    assert near(ob.normal_at(w, t, (0, 0, 0), 0.45, 0.25), (-0.5547, 0.83205, 0))
-    c, _ = ob.eval_list(w, ((-0.2, 0.3, -2), (0, 0, 1)), [(1., t, 0.45, 0.25)], 0)
-    assert near(c.normal_vector, (-0.5547, 0.83205, 0))
+    k = KAT["smooth_triangle"]
+    ts, uv = ob.local_intersect(w, t, *k["ray"])
+    assert len(ts) == 1 and abs(uv[0][0] - k["u"]) < EPS and abs(uv[0][1] - k["v"]) < EPS
+    assert near(ob.normal_at(w, t, (0, 0, 0), k["u"], k["v"]), k["normal"])
+    c, _ = ob.eval_list(w, ray_of(k["ray"]), [(1., t, k["u"], k["v"])], 0)
+    assert near(c.normal_vector, k["normal"])
 
 
 def test_smooth_triangle_uses_first_intersections_uv():  # F5: intersection.rs:40 passes intersections[0]
@@ -390,16 +403,16 @@ def test_world_to_object_and_normal_to_world():  # shape.rs:678-730
     g2.add_child(s)
     g1.add_child(g2)
     w = world_of(g1)
-    assert near(ob.world_to_object(w, s, (-2, 0, -10)), (0, 0, -1))
+    k = KAT["parent_chain"]
+    assert near(ob.world_to_object(w, s, k["world_to_object"]["point"]), k["world_to_object"]["expected"])
     g1 = Shape.group().set_transform(rotate(PI / 2, Axis.Y))
     g2 = Shape.group().set_transform(scale(1, 2, 3))
     s = Shape.sphere().set_transform(translate(5, 0, 0))
     g2.add_child(s)
     g1.add_child(g2)
     w = world_of(g1)
-    r3 = math.sqrt(3) / 3
-    assert near(ob.normal_to_world(w, s, (r3, r3, r3)), (0.28571, 0.42857, -0.85714))
-    assert near(ob.normal_at(w, s, (1.7321, 1.1547, -5.5774)), (0.2857, 0.42854, -0.85716))
+    assert near(ob.normal_to_world(w, s, k["normal_to_world"]["normal"]), k["normal_to_world"]["expected"])
+    assert near(ob.normal_at(w, s, k["normal_at"]["point"]), k["normal_at"]["expected"])
 
 
 def test_group_intersections():  # group.rs:192-241
@@ -410,12 +423,14 @@ def test_group_intersections():  # group.rs:192-241
     s3 = Shape.sphere().set_transform(translate(5, 0, 0))
     for s in (s1, s2, s3):
         g.add_child(s)
-    xs = ob.intersect_world(world_of(g), ((0, 0, -5), (0, 0, 1)))
-    assert [i for _, i in xs] == [s2.get_id(), s2.get_id(), s1.get_id(), s1.get_id()]
+    k = KAT["group"]
+    xs = ob.intersect_world(world_of(g), ray_of(k["three_spheres_ray"]))
+    ids = {"s1": s1.get_id(), "s2": s2.get_id()}
+    assert [i for _, i in xs] == [ids[n] for n in k["order"]]
     g = Shape.group().set_transform(scale(2, 2, 2))
     s = Shape.sphere().set_transform(translate(5, 0, 0))
     g.add_child(s)
-    assert len(ob.intersect_world(world_of(g), ((10, 0, -10), (0, 0, 1)))) == 2
+    assert len(ob.intersect_world(world_of(g), ray_of(k["scaled_group_ray"]))) == k["scaled_group_count"]
 
 
 def test_group_box_gate_skips_children():  # group.rs:265-300 (TestShape replaced by a sphere the box excludes)
@@ -423,8 +438,32 @@ def test_group_box_gate_skips_children():  # group.rs:265-300 (TestShape replace
     s = Shape.sphere()
     g.add_child(s)
     w = world_of(g)
-    assert ob.intersect_world(w, ((0, 0, -5), (0, 1, 0))) == []
-    assert len(ob.intersect_world(w, ((0, 0, -5), (0, 0, 1)))) == 2
+    k = KAT["group"]
+    assert ob.intersect_world(w, ray_of(k["gate_miss_ray"])) == []
+    assert len(ob.intersect_world(w, ray_of(k["gate_hit_ray"]))) == 2
+    # the gate itself (what the reference observes through TestShape's SAVED_RAY): Bound::intersects on the group's box
+    box = np.array(w.flatten().contents.group_box[0:6])
+    assert near(box, (-1, -1, -1, 1, 1, 1))   # TestShape and Sphere have the same bounds (shape.rs:516-519, sphere.rs:80-83)
+    assert not ob.bound_intersects(box[:3], box[3:], *k["gate_miss_ray"])
+    assert ob.bound_intersects(box[:3], box[3:], *k["gate_hit_ray"])
+
+
+def test_group_bounds():  # group.rs:244-262, shape.rs:748-759
+    k = KAT["group_bounds"]
+    sphere = Shape.sphere().set_transform(translate(2., 5., -3.) * scale(2., 2., 2.))
+    cylinder = Shape.cylinder().set_minimum(-2.).set_maximum(2.).set_transform(translate(-4., -1., 4.) * scale(0.5, 1., 0.5))
+    g = Shape.group()
+    g.add_child(sphere)
+    g.add_child(cylinder)
+    lo, hi = g.bounds_of()
+    assert near(lo, k["minimum"]) and near(hi, k["maximum"])
+    # what the device's gate receives is this very box
+    wg = world_of(g)   # (keep the world alive: the flattened tables belong to it)
+    box = np.array(wg.flatten().contents.group_box[0:6])
+    assert near(box[:3], k["minimum"]) and near(box[3:], k["maximum"])
+    s = Shape.sphere().set_transform(translate(1., -3., 5.) * scale(0.5, 2., 4.))
+    lo, hi = s.parent_space_bounds_of()
+    assert near(lo, k["parent_space_sphere"]["minimum"]) and near(hi, k["parent_space_sphere"]["maximum"])
 
 
 def test_material_comes_from_root_ancestor():  # F7: shape.rs:163-184
@@ -441,29 +480,18 @@ def test_hexagon_parity_of_gates():  # lib.rs:91-126: finite group boxes on two 
 
 
 # ------------------------------------------------------------------ bound.rs
-BOX_DIRS = [(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1), (0, 0, 1), (2, 4, 6), (6, 2, 4), (4, 6, 2),
-            (0, 0, -1), (0, -1, 0), (-1, 0, 0)]
-BOX_EXPECT = [True] * 7 + [False] * 6
-
-
-def test_bound_intersects_unit_box():  # bound.rs:279-309
-    origins = [(5, 0.5, 0), (-5, 0.5, 0), (0.5, 5, 0), (0.5, -5, 0), (0.5, 0, 5), (0.5, 0, -5), (0, 0.5, 0), (-2, 0, 0),
-               (0, -2, 0), (0, 0, -2), (2, 0, 2), (0, 2, 2), (2, 2, 0)]
-    got = [ob.bound_intersects((-1, -1, -1), (1, 1, 1), o, norm(d)) for o, d in zip(origins, BOX_DIRS)]
-    assert got == BOX_EXPECT
-
-
-def test_bound_intersects_noncubic_box():  # bound.rs:312-342
-    origins = [(1.5, 1, 2), (-5, -1, 4), (7, 6, 5), (9, -5, 6), (8, 2, 1.2), (6, 0, -5), (8, 1, 3.5), (9, -1, -8), (8, 3, -4),
-               (9, -1, -2), (4, 0, 9), (8, 6, -1), (1.2, 5, 4)]
-    got = [ob.bound_intersects((5, -2, 0), (11, 4, 7), o, norm(d)) for o, d in zip(origins, BOX_DIRS)]
-    assert got == BOX_EXPECT
+def test_bound_intersects_tables():  # bound.rs:279-342
+    k = KAT["bound_intersects"]
+    for which in ("unit_box", "noncubic_box"):
+        b = k[which]
+        got = [ob.bound_intersects(b["min"], b["max"], o, norm(d)) for o, d in zip(b["origins"], k["directions"])]
+        assert got == k["expected"]
 
 
 # ------------------------------------------------------------------ csg.rs
 def test_csg_truth_table():  # csg.rs:176-220
-    table = {"union": [0, 1, 0, 1, 0, 0, 1, 1], "intersection": [1, 0, 1, 0, 1, 1, 0, 0], "difference": [0, 1, 0, 1, 1, 1, 0, 0]}
-    for op, results in table.items():
+    for op in ("union", "intersection", "difference"):
+        results = KAT["csg_truth_table"][op]
         i = 0
         for lhit in (True, False):
             for inl in (True, False):
@@ -476,11 +504,29 @@ def test_csg_truth_table():  # csg.rs:176-220
 def test_csg_ray_misses_and_hits():  # csg.rs:242-273
     s, c = Shape.sphere(), Shape.cube()
     csg = Shape.csg("union", s, c)
-    assert ob.intersect_world(world_of(csg), ((0, 2, -5), (0, 0, 1))) == []
-    s, c = Shape.sphere(), Shape.cube().set_transform(translate(0, 0, 0.5))
+    k = KAT["csg_rays"]
+    assert ob.intersect_world(world_of(csg), ray_of(k["miss_ray"])) == []
+    s, c = Shape.sphere(), Shape.cube().set_transform(translate(*k["cube_translate"]))
     csg = Shape.csg("union", s, c)
-    xs = ob.intersect_world(world_of(csg), ((0, 0, -5), (0, 0, 1)))
-    assert len(xs) == 2 and near(xs[0][0], 4.) and xs[0][1] == s.get_id() and near(xs[1][0], 6.5) and xs[1][1] == c.get_id()
+    xs = ob.intersect_world(world_of(csg), ray_of(k["hit_ray"]))
+    assert len(xs) == 2 and near(xs[0][0], k["t"][0]) and xs[0][1] == s.get_id() and near(xs[1][0], k["t"][1]) and xs[1][1] == c.get_id()
+
+
+def test_csg_filter_intersections_literal_list():  # csg.rs:223-240: filter_intersections on the literal list (1 s1, 2 s2, 3 s1, 4 s2)
+    import ctypes as C
+    k = KAT["csg_filter"]
+    ob.olib.orc_filter_intersections.argtypes = [ob.DESC, C.c_int, C.c_int, ob.c_dp, ob.c_ip, ob.c_ip]
+    for op, keep in k["expected"].items():
+        s1, s2 = Shape.sphere(), Shape.cube()
+        csg = Shape.csg(op, s1, s2)
+        w = world_of(csg)
+        names = {"s1": w.node_of(s1), "s2": w.node_of(s2)}
+        t = np.array([x[0] for x in k["xs"]], dtype=np.float64)
+        node = np.array([names[x[1]] for x in k["xs"]], dtype=np.int32)
+        kept = np.zeros(len(t), dtype=np.int32)
+        n = ob.olib.orc_filter_intersections(w.flatten(), w.node_of(csg), len(t), t.ctypes.data_as(ob.c_dp), node.ctypes.data_as(ob.c_ip),
+                                             kept.ctypes.data_as(ob.c_ip))
+        assert n == 2 and list(kept[:2]) == keep
 
 
 def test_csg_filtering_through_real_rays():  # csg.rs:223-240 (lists (1,2,3,4) -> union 0,3 / intersection 1,2 / difference 0,1)
@@ -502,24 +548,17 @@ def lighting_world(light_pos, material=None):
 
 
 def test_lighting():  # material.rs:161-260
-    P, N = (0, 0, 0), (0, 0, -1)
-    w, s = lighting_world((0, 0, -10))
-    assert near(ob.lighting(w, s, 0, P, (0, 0, -1), N, False), (1.9, 1.9, 1.9))
-    assert near(ob.lighting(w, s, 0, P, (0, S2 / 2, -S2 / 2), N, False), (1., 1., 1.))
-    w, s = lighting_world((0, 10, -10))
-    assert near(ob.lighting(w, s, 0, P, (0, 0, -1), N, False), (0.7364, 0.7364, 0.7364))
-    assert near(ob.lighting(w, s, 0, P, (0, -S2 / 2, -S2 / 2), N, False), (1.6364, 1.6364, 1.6364))
-    w, s = lighting_world((0, 0, 10))
-    assert near(ob.lighting(w, s, 0, P, (0, 0, -1), N, False), (0.1, 0.1, 0.1))
-    w, s = lighting_world((0, 0, -10))
-    assert near(ob.lighting(w, s, 0, P, (0, 0, -1), N, True), (0.1, 0.1, 0.1))
+    k = KAT["lighting"]
+    for c in k["cases"]:
+        w, s = lighting_world(c["light"])
+        assert near(ob.lighting(w, s, 0, k["position"], c["eye"], k["normal"], c["shadow"]), c["color"])
 
 
 def test_lighting_with_pattern():  # material.rs:262-277
     m = Material(ambient=1., diffuse=0., specular=0.).with_pattern(Pattern.striped(rt.WHITE, rt.BLACK))
     w, s = lighting_world((0, 0, -10), m)
-    assert near(ob.lighting(w, s, 0, (0.9, 0, 0), (0, 0, -1), (0, 0, -1), False), (1, 1, 1))
-    assert near(ob.lighting(w, s, 0, (1.1, 0, 0), (0, 0, -1), (0, 0, -1), False), (0, 0, 0))
+    for c in KAT["lighting"]["stripe"]:
+        assert near(ob.lighting(w, s, 0, c["point"], (0, 0, -1), (0, 0, -1), False), c["color"])
 
 
 # ------------------------------------------------------------------ pattern.rs
@@ -532,30 +571,30 @@ def pat_world(pattern, transform=None):
 
 def test_stripe_pattern():  # pattern.rs:226-290
     w, s = pat_world(Pattern.striped(rt.WHITE, rt.BLACK))
-    for p, c in [((0, 0, 0), 1), ((0, 1, 0), 1), ((0, 2, 0), 1), ((0, 0, 1), 1), ((0, 0, 2), 1), ((0.9, 0, 0), 1), ((1, 0, 0), 0),
-                 ((-0.1, 0, 0), 0), ((-1, 0, 0), 0), ((-1.1, 0, 0), 1)]:
+    for p, c in KAT["patterns"]["stripe"]:
         assert near(ob.pattern_at_shape(w, s, p), (c, c, c))
 
 
 def test_pattern_transforms():  # pattern.rs:292-350
     w, s = pat_world(Pattern.test(), scale(2, 2, 2))
-    assert near(ob.pattern_at_shape(w, s, (2, 3, 4)), (1, 1.5, 2))
+    k = KAT["patterns"]
+    assert near(ob.pattern_at_shape(w, s, k["object_scale2"]["point"]), k["object_scale2"]["color"])
     w, s = pat_world(Pattern.test().set_transform(scale(2, 2, 2)))
-    assert near(ob.pattern_at_shape(w, s, (2, 3, 4)), (1, 1.5, 2))
+    assert near(ob.pattern_at_shape(w, s, k["pattern_scale2"]["point"]), k["pattern_scale2"]["color"])
     w, s = pat_world(Pattern.test().set_transform(translate(0.5, 1, 1.5)), scale(2, 2, 2))
-    assert near(ob.pattern_at_shape(w, s, (2.5, 3, 3.5)), (0.75, 0.5, 0.25))
+    assert near(ob.pattern_at_shape(w, s, k["both"]["point"]), k["both"]["color"])
 
 
 def test_gradient_ring_checkers():  # pattern.rs:352-426
     w, s = pat_world(Pattern.gradient(rt.WHITE, rt.BLACK))
-    for x, c in [(0, 1), (0.25, 0.75), (0.5, 0.5), (0.75, 0.25)]:
+    k = KAT["patterns"]
+    for x, c in k["gradient"]:
         assert near(ob.pattern_at_shape(w, s, (x, 0, 0)), (c, c, c))
     w, s = pat_world(Pattern.ring(rt.WHITE, rt.BLACK))
-    for p, c in [((0, 0, 0), 1), ((1, 0, 0), 0), ((0, 0, 1), 0), ((0.708, 0, 0.708), 0)]:
+    for p, c in k["ring"]:
         assert near(ob.pattern_at_shape(w, s, p), (c, c, c))
     w, s = pat_world(Pattern.checkered(rt.WHITE, rt.BLACK))
-    for p, c in [((0, 0, 0), 1), ((0.99, 0, 0), 1), ((1.01, 0, 0), 0), ((0, 0.99, 0), 1), ((0, 1.01, 0), 0), ((0, 0, 0.99), 1),
-                 ((0, 0, 1.01), 0)]:
+    for p, c in k["checkers"]:
         assert near(ob.pattern_at_shape(w, s, p), (c, c, c))
 
 
