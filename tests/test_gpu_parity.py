@@ -266,7 +266,7 @@ def _shared_id_worlds():
                                                     ["f 1 %d %d" % (2 + k, 2 + (k + 1) % 10) for k in range(10)]) + "\n")
                 fan.set_material(glass)
                 c = Shape.csg(op, fan, fan.clone().set_transform(translate(0.3, 0., 0.2)))
-            c.set_transform(translate(0., 0.2, 0.) * rotate(Axis.Y, 0.3))
+            c.set_transform(translate(0., 0.2, 0.) * rotate(0.3, Axis.Y))
             w.objects.append(c)
             yield op, variant, w
 

@@ -36,6 +36,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(rt.HOST_SYMBOLS) == _declared("rt_host.h")
 
 
+def test_integration_md_binds_every_declared_symbol_and_builds_every_source():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = sorted(set(re.findall(r"pub fn (rt_[a-z0-9_]+)\(", text)))
+    assert bound == _declared("rt_abi.h")
+    # the build.rs recipe must name every translation unit of csrc/ (a missing one is an undefined symbol at load time)
+    csrc = os.path.join(ROOT, "ray-tracer_amd", "csrc")
+    units = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".cpp")))
+    recipe = text[text.index("build.rs"):text.index("## 2.")]
+    assert all(("csrc/" + u) in recipe for u in units), units
+
+
 def test_struct_sizes_match_the_header():
     # rt_camera_desc: 4 int32 + 16 + 3 doubles; rt_render_opts: 4 int32 + pointer; rt_stats: see rt_abi.h
     assert C.sizeof(rt.CameraDesc) == 16 + 19 * 8
