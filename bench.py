@@ -36,7 +36,7 @@ F_LIGHTING = 75       # Material::lighting per light (+ one powf)
 F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
 B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
 # bytes of level state read + written per ray by each stage (rt_device.h: Level columns touched)
-B_RAY_IO = {"k_trace": 48 + 17, "k_trace_hit": 56, "shadow": 4 + 48 + 1, "container": 4 + 64 + 16 + 4, "k_queue+k_finish": 4 + 16 + 150}
+B_RAY_IO = {"k_trace": 48 + 17, "k_trace_hit": 56, "shadow": 4 + 48 + 1, "container": 4 + 64 + 16 + 4, "k_queue+k_spawn": 4 + 16 + 60, "k_shade": 4 + 4 + 72 + 16 + 1 + 24 + 24}
 
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
@@ -184,7 +184,7 @@ def main():
     st = rt.Stats()
     step(st)
     n_ev = 5
-    ev = {"ms_trace": 0.0, "ms_shadow": 0.0, "ms_collect": 0.0, "ms_shade": 0.0, "ms_total": 0.0}
+    ev = {"ms_trace": 0.0, "ms_collect": 0.0, "ms_shade": 0.0, "ms_resolve": 0.0, "ms_total": 0.0}
     for _ in range(n_ev):
         s2 = rt.Stats()
         step(s2)
@@ -203,22 +203,24 @@ def main():
 
     if rank == 0:
         n_lights = len(w.lights)
-        # k_secondary = one launch per level serving the shadow queue and the container (n1/n2) queue; the instrumented
-        # run counts the two queues' work apart (sc.work_shadow / sc.work_container), the timed runs launch them together
-        w_sec = [a + b for a, b in zip(sc.work_shadow, sc.work_container)]
-        works = {"k_trace": list(sc.work_trace), "k_secondary": w_sec}
-        ms = {"k_trace": ev["ms_trace"], "k_secondary": ev["ms_shadow"] + ev["ms_collect"], "k_queue+k_finish": ev["ms_shade"]}
-        launches = {"k_trace": st.n_trace_launches, "k_secondary": st.n_shadow_launches,
-                    "k_queue+k_finish": 2 * st.n_trace_launches}
+        # k_trace = one launch per level: the closest hits of level d AND the shadow rays of level d-1 (+ one launch for
+        # the last level's shadow rays); k_walk = the n1/n2 container walks of a level.  The instrumented run counts
+        # the three kinds of work apart (work_trace / work_shadow / work_container).
+        w_tr = [a + b for a, b in zip(sc.work_trace, sc.work_shadow)]
+        works = {"k_trace": w_tr, "k_walk": list(sc.work_container)}
+        ms = {"k_trace": ev["ms_trace"], "k_walk": ev["ms_collect"], "k_queue+k_spawn": ev["ms_shade"], "k_shade": ev["ms_resolve"]}
+        launches = {"k_trace": st.n_trace_launches, "k_walk": st.n_shadow_launches,
+                    "k_queue+k_spawn": 2 * st.n_trace_launches - 3, "k_shade": st.n_trace_launches - 1}
         traced = st.rays_primary + st.rays_reflect + st.rays_refract
         flops = {k: work_flops(v) for k, v in works.items()}
         flops["k_trace"] += st.shaded_nodes * F_PREPARE   # prepare_computations runs in k_trace's epilogue
-        flops["k_queue+k_finish"] = st.shaded_nodes * F_LIGHTING * n_lights + st.rays_reflect * F_REFLECT + \
-            st.rays_refract * (F_REFRACT + F_SCHLICK)
-        nbytes = {"k_trace": work_bytes(works["k_trace"]) + traced * B_RAY_IO["k_trace"] + st.shaded_nodes * B_RAY_IO["k_trace_hit"],
-                  "k_secondary": work_bytes(w_sec) + st.rays_shadow * B_RAY_IO["shadow"] + st.rays_container * B_RAY_IO["container"],
-                  "k_queue+k_finish": traced * B_RAY_IO["k_queue+k_finish"]}
-        dom = max(("k_trace", "k_secondary"), key=lambda k: ms[k])
+        flops["k_queue+k_spawn"] = st.rays_reflect * F_REFLECT + st.rays_refract * F_REFRACT
+        flops["k_shade"] = st.shaded_nodes * F_LIGHTING * n_lights + st.rays_refract * F_SCHLICK
+        nbytes = {"k_trace": work_bytes(works["k_trace"]) + traced * B_RAY_IO["k_trace"] + st.shaded_nodes * B_RAY_IO["k_trace_hit"] +
+                  st.rays_shadow * B_RAY_IO["shadow"],
+                  "k_walk": work_bytes(works["k_walk"]) + st.rays_container * B_RAY_IO["container"],
+                  "k_queue+k_spawn": traced * B_RAY_IO["k_queue+k_spawn"], "k_shade": traced * B_RAY_IO["k_shade"]}
+        dom = max(("k_trace", "k_walk"), key=lambda k: ms[k])
         n_launch = max(launches[dom], 1)
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

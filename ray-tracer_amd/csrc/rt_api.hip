@@ -89,32 +89,19 @@ struct rt_scene {
     int scene_class = 0;  // SC_CSG | SC_CULL: which traversal kernel variants this scene runs
     int n_lights = 0;
     std::vector<LevelStore> levels;
+    // one block of CNT_TOTAL device counters per recursion level + one for the launch after the last level; the host
+    // mirror (pinned) holds the CNT_COUNT plain counters of every block
     unsigned long long* d_counters = nullptr;
-    unsigned long long* h_counters = nullptr;  // pinned
+    unsigned long long* h_counters = nullptr;
+    int counter_blocks = 0;
     GrowBuf out_rgb, out_id, out_flags, frame_rgb, frame_id, frame_flags, in_a, in_b, misc_a, misc_b, misc_c;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    // Sub-frame chains: a shard is cut into up to MAX_CHAINS interleaved sub-shards, each with its own level queues,
-    // counters and stream, so that one chain's launch tails (a handful of wavefronts finishing heavy chunks) overlap
-    // the other chains' bulk.  Chain 0 lives in the fields above; `chain_swap` exchanges them with a parked chain.
-    struct Parked {
-        std::vector<LevelStore> levels;
-        unsigned long long* d_counters = nullptr;
-        unsigned long long* h_counters = nullptr;
-        int32_t* spill = nullptr;  // each chain spills traversal stacks into its own area: chains run concurrently
-        hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
-    };
-    static constexpr int MAX_CHAINS = 4;
-    Parked parked[MAX_CHAINS];  // [0] unused except for `done`
-    hipEvent_t ev_in = nullptr;
-    // The enqueue of a whole frame (all chains, ~45 launches each) costs the host about as long as the GPU needs to
-    // run it, which kept the chains from overlapping.  So the enqueue is captured once into a HIP graph and replayed
-    // with one call while everything it bakes in stays the same (camera, shard, depth, output pointers, queue
-    // blocks): `graph_key` is the byte image of those.
+    std::vector<hipEvent_t> events;  // timing pool of the rt_stats path (events on the launch stream)
+    // The enqueue of a whole frame (~35 launches) is captured once into a HIP graph and replayed with one call while
+    // everything it bakes in stays the same (camera, shard, depth, output pointers, queue blocks): `graph_key` is the
+    // byte image of those.
     hipGraphExec_t graph_exec = nullptr;
     std::string graph_key;
     bool use_graph = true;
-    int max_chains = 2;  // measured on the 1080p teapot frame: 1 chain 2.14 ms, 2 chains 2.07 ms, 4 chains 3.09 ms (RT_AMD_CHAINS overrides)
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
     int n_cus = 1;
@@ -123,38 +110,24 @@ struct rt_scene {
 
 namespace {
 
-// While alive, chain k's queues and counters sit in the scene's chain-0 fields (and chain 0's are parked in slot k).
-struct ChainScope {
-    rt_scene* s;
-    int k;
-    ChainScope(rt_scene* scene, int chain) : s(scene), k(chain) { swap(); }
-    ~ChainScope() { swap(); }
-    void swap() {
-        if (k == 0) return;
-        std::swap(s->levels, s->parked[k].levels);
-        std::swap(s->d_counters, s->parked[k].d_counters);
-        std::swap(s->h_counters, s->parked[k].h_counters);
-        std::swap(s->ds.spill, s->parked[k].spill);
+// Timing events that live for one call.
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr, r0 = nullptr, r1 = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() {
+        for (hipEvent_t e : {e0, e1, r0, r1})
+            if (e) (void)hipEventDestroy(e);
     }
 };
-
-// A device allocation / a pair of timing events that live for one call.
+// A device allocation that lives for one call.
 struct DeviceTemp {
     void* p = nullptr;
     DeviceTemp() = default;
     DeviceTemp(const DeviceTemp&) = delete;
     DeviceTemp& operator=(const DeviceTemp&) = delete;
     ~DeviceTemp() { if (p) (void)hipFree(p); }
-};
-struct EventPair {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    EventPair() = default;
-    EventPair(const EventPair&) = delete;
-    EventPair& operator=(const EventPair&) = delete;
-    ~EventPair() {
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
 };
 
 int grow(GrowBuf& b, size_t bytes) {
@@ -194,7 +167,6 @@ std::vector<double> rows3(const double* m16, int n) {
 
 int ensure_level(rt_scene* s, size_t idx, long long cap) {
     if (s->levels.size() <= idx) s->levels.resize(idx + 1);
-    s->levels.reserve(64);
     LevelStore& ls = s->levels[idx];
     if (ls.cap >= cap && ls.block) return RT_OK;
     if (ls.block) HIP_TRY(hipFree(ls.block));
@@ -208,8 +180,7 @@ int ensure_level(rt_scene* s, size_t idx, long long cap) {
     HIP_TRY(hipMalloc(&ls.block, bytes));
     double* dp = static_cast<double*>(ls.block);
     double** dfields[nd] = {&ls.L.ox, &ls.L.oy, &ls.L.oz, &ls.L.dx, &ls.L.dy, &ls.L.dz, &ls.L.ht, &ls.L.hu, &ls.L.hv,
-                            &ls.L.sr, &ls.L.sg, &ls.L.sb, &ls.L.k_refl, &ls.L.k_transp, &ls.L.k_schlick, &ls.L.cr,
-                            &ls.L.cg, &ls.L.cb};
+                            &ls.L.px, &ls.L.py, &ls.L.pz, &ls.L.nx, &ls.L.ny, &ls.L.nz, &ls.L.cr, &ls.L.cg, &ls.L.cb};
     for (size_t k = 0; k < nd; ++k) *dfields[k] = dp + size_t(c) * k;
     int32_t* ip = reinterpret_cast<int32_t*>(dp + size_t(c) * nd);
     ls.L.hkey = ip;
@@ -221,31 +192,67 @@ int ensure_level(rt_scene* s, size_t idx, long long cap) {
     ls.L.flags = reinterpret_cast<uint8_t*>(ip + size_t(c) * ni);
     ls.L.flags32 = reinterpret_cast<uint32_t*>(ls.L.flags);
     ls.L.shadowed = ls.L.flags + size_t(c);
-    ls.L.px = ls.L.sr; ls.L.py = ls.L.sg; ls.L.pz = ls.L.sb;
-    ls.L.nx = ls.L.k_refl; ls.L.ny = ls.L.k_transp; ls.L.nz = ls.L.k_schlick;
     ls.cap = c;
+    return RT_OK;
+}
+
+// Counter blocks for a frame of `blocks` levels (+ host mirror).
+int ensure_counters(rt_scene* s, int blocks) {
+    if (blocks <= s->counter_blocks) return RT_OK;
+    const int want = std::max(blocks, 16);
+    if (s->d_counters) HIP_TRY(hipFree(s->d_counters));
+    if (s->h_counters) HIP_TRY(hipHostFree(s->h_counters));
+    s->d_counters = nullptr;
+    s->h_counters = nullptr;
+    s->counter_blocks = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counters), size_t(want) * CNT_TOTAL * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), size_t(want) * CNT_COUNT * sizeof(unsigned long long)));
+    s->counter_blocks = want;
     return RT_OK;
 }
 
 inline unsigned blocks_for(long long n) { return unsigned((n + BLOCK - 1) / BLOCK); }
 
-struct Timer {  // accumulates device time of bracketed launches when enabled
+// Device time of bracketed launches by kernel class, with HIP events on the launch stream.  Nothing waits while the
+// frame is being enqueued: the pairs are read after the caller has waited for the stream.
+struct Timer {
     rt_scene* s;
     hipStream_t st;
     bool on;
-    double* acc = nullptr;
+    struct Pair { double* acc; size_t e0, e1; };
+    std::vector<Pair> pairs;
+    size_t used = 0;
+    double* cur = nullptr;
+    size_t cur_e0 = 0;
+    size_t take() {
+        if (used == s->events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return 0; }
+            s->events.push_back(e);
+        }
+        return used++;
+    }
     void begin(double* a) {
         if (!on) return;
-        acc = a;
-        (void)hipEventRecord(s->ev[0], st);
+        cur = a;
+        cur_e0 = take();
+        if (on) (void)hipEventRecord(s->events[cur_e0], st);
     }
     void end() {
+        if (!on || !cur) return;
+        size_t e1 = take();
         if (!on) return;
-        (void)hipEventRecord(s->ev[1], st);
-        (void)hipEventSynchronize(s->ev[1]);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
-        *acc += double(ms);
+        (void)hipEventRecord(s->events[e1], st);
+        pairs.push_back({cur, cur_e0, e1});
+        cur = nullptr;
+    }
+    void collect() {  // after the stream has been waited for
+        if (!on) return;
+        for (const Pair& p : pairs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s->events[p.e0], s->events[p.e1]) == hipSuccess) *p.acc += double(ms);
+        }
+        pairs.clear();
     }
 };
 
@@ -277,25 +284,24 @@ inline long long chunks_for(long long n) { return (n + 63) / 64; }  // small lau
         case 2: CALL(2); break;     \
         default: CALL(3); break;    \
     }
+// k_trace: the closest hits of level L (n rays, or n_dev's count clamped to n; n == 0: none) and the shadow rays of
+// the hits of level P queued in `prev` (null: none); `prev_upper` bounds P's hit count for the grid size.
 template <bool COUNT>
 int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, int remaining,
-                 unsigned long long* ctr) {
+                 unsigned long long* ctr, const Level& P, unsigned long long* prev, long long prev_upper) {
+    const long long chunks = chunks_for(n) + (prev ? chunks_for(prev_upper * (s->n_lights > 0 ? s->n_lights : 1)) : 0);
     int rc = RT_OK;
-#define RT_CALL(SC)                                                                                                          \
-    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr)  \
-                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks_for(n), s->ds, L, n, n_dev, remaining, ctr)
+#define RT_CALL(SC)                                                                                                            \
+    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)    \
+                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
     return rc;
 }
 template <bool COUNT>
-int launch_secondary(rt_scene* s, hipStream_t st, const Level& L, long long n, int phases, unsigned long long* ctr) {
-    // upper bound of the chunk count: the queue lengths live on the device
-    const long long upper = chunks_for(n * (s->n_lights > 0 ? s->n_lights : 1)) + chunks_for(n);
+int launch_walk(rt_scene* s, hipStream_t st, const Level& L, long long n_upper, unsigned long long* ctr) {
     int rc = RT_OK;
-#define RT_CALL(SC)                                                                                              \
-    rc = s->any_transparent ? launch_trav(s, st, k_secondary<SC, COUNT, true>, upper, s->ds, L, ctr, phases)   \
-                            : launch_trav(s, st, k_secondary<SC, COUNT, false>, upper, s->ds, L, ctr, phases)
+#define RT_CALL(SC) rc = launch_trav(s, st, k_walk<SC, COUNT>, chunks_for(n_upper), s->ds, L, ctr)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
     return rc;
@@ -313,171 +319,177 @@ inline void launch_queue(hipStream_t st, const Level& L, long long n, const unsi
     }
 }
 
-// Maximum number of recursion levels a frame can be enqueued for without a host round trip per level
-// (one counter block per level).
-constexpr int ASYNC_LEVELS = 34;
+inline unsigned long long* counter_block(rt_scene* s, int d) { return s->d_counters + size_t(d) * CNT_TOTAL; }
 
-// The whole frame in one go: every level's launches are enqueued back to back, each level reads its ray count from
-// the counter block of the level before it, and the host waits once, at the end.  Possible when the per-level
-// queues already exist (a synchronous frame has sized them); if a level spawned more rays than its queue holds —
-// the view changed — nothing was written out of bounds and the caller falls back to the synchronous walk, which
-// grows the queues.  Returns RT_OK with *overflow set in that case.
-int enqueue_levels_async(rt_scene* s, hipStream_t st, long long n0, int max_depth) {
-    const int D = max_depth;
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, size_t(D + 1) * CNT_TOTAL * sizeof(unsigned long long), st));
-    const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
-    for (int d = 0; d <= D; ++d) {
-        const int remaining = D - d;
-        const Level& L = s->levels[size_t(d)].L;
-        const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
-        const long long n = d == 0 ? n0 : s->levels[size_t(d)].cap;
-        const long long next_cap = remaining > 0 ? s->levels[size_t(d) + 1].cap : 0;
-        unsigned long long* ctr = s->d_counters + size_t(d) * CNT_TOTAL;
-        const unsigned long long* n_dev = d == 0 ? nullptr : s->d_counters + size_t(d - 1) * CNT_TOTAL + CNT_NEXT;
-        int rc = launch_trace<false>(s, st, L, n, n_dev, remaining, ctr);
-        if (rc != RT_OK) return rc;
-        launch_queue(st, L, n, n_dev, next_cap, ctr);
-        if (want) {
-            rc = launch_secondary<false>(s, st, L, n, want, ctr);
-            if (rc != RT_OK) return rc;
-        }
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, n_dev, remaining);
-    }
-    for (int d = D; d >= 0; --d) {
-        const Level& L = s->levels[size_t(d)].L;
-        const Level& N = d < D ? s->levels[size_t(d) + 1].L : L;
-        const long long n = d == 0 ? n0 : s->levels[size_t(d)].cap;
-        const unsigned long long* n_dev = d == 0 ? nullptr : s->d_counters + size_t(d - 1) * CNT_TOTAL + CNT_NEXT;
-        hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n)), dim3(BLOCK), 0, st, L, N, n, n_dev, d < D ? 1 : 0);
-    }
-    HIP_TRY(hipGetLastError());
-    // one strided copy: the CNT_COUNT plain counters of every level block
-    HIP_TRY(hipMemcpy2DAsync(s->h_counters, CNT_COUNT * sizeof(unsigned long long), s->d_counters, CNT_TOTAL * sizeof(unsigned long long),
-                             CNT_COUNT * sizeof(unsigned long long), size_t(D + 1), hipMemcpyDeviceToHost, st));
-    return RT_OK;
-}
-// after the stream has been waited for: did every level fit its queue?
-bool levels_async_overflowed(rt_scene* s, int max_depth) {
-    for (int d = 0; d < max_depth; ++d)
-        if ((long long)s->h_counters[size_t(d) * CNT_COUNT + CNT_NEXT] > s->levels[size_t(d) + 1].cap) return true;
-    return false;
-}
-bool levels_sized_for_async(rt_scene* s, int max_depth, bool counters, rt_stats* stats) {
-    if (stats || counters || max_depth < 0 || max_depth + 1 > ASYNC_LEVELS || s->levels.size() <= size_t(max_depth)) return false;
+// Do levels 0..max_depth have queues (so that a whole frame can be enqueued without a host round trip per level)?
+bool levels_sized(rt_scene* s, int max_depth) {
+    if (max_depth < 0 || s->levels.size() <= size_t(max_depth)) return false;
     for (int d = 0; d <= max_depth; ++d)
         if (!s->levels[size_t(d)].block) return false;
     return true;
 }
-int run_levels_async(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool* overflow) {
-    int rc = enqueue_levels_async(s, st, n0, max_depth);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    *overflow = levels_async_overflowed(s, max_depth);
-    return RT_OK;
+// after the stream has been waited for: did every level fit its queue?
+bool levels_overflowed(rt_scene* s, int max_depth) {
+    for (int d = 0; d < max_depth; ++d)
+        if ((long long)s->h_counters[size_t(d) * CNT_COUNT + CNT_NEXT] > s->levels[size_t(d) + 1].cap) return true;
+    return false;
 }
 
-
-// color_at for every ray already sitting in level 0 (n0 slots).  Leaves resolved colours in level 0.
-int run_levels(rt_scene* s, hipStream_t st, long long n0, int max_depth, bool counters, rt_stats* stats) {
-    if (levels_sized_for_async(s, max_depth, counters, stats)) {
-        bool overflow = false;
-        int rc = run_levels_async(s, st, n0, max_depth, &overflow);
-        if (rc != RT_OK || !overflow) return rc;
-    }
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_TOTAL * sizeof(unsigned long long), st));
-    Timer tm{s, st, stats != nullptr};
-    std::vector<long long> counts;
-    unsigned long long work_prev[RT_WORK_COUNT] = {0};
-    long long total_shaded = 0, total_walks = 0;
+// color_at for every ray already sitting in level 0 (n0 slots): enqueues the whole ray tree and, bottom-up, its shading;
+// resolved colours end up in level 0's cr/cg/cb.
+//   sized == false (`sync` walk): a host round trip per level reads the level's ray count and sizes the next queue —
+//     the first frame of a scene / view, and the fall-back when a queue overflowed.
+//   sized == true: every level reads its count from the counter block of the level before it, grids are sized by queue
+//     capacity, nothing waits; a level that spawned more rays than the next queue holds wrote nothing out of bounds, and
+//     the caller — after waiting for the stream — sees it with levels_overflowed() and repeats the frame with the walk.
+// Either way the plain counters of every block are copied to h_counters at the end (stream-ordered).
+template <bool COUNT>
+int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, Timer& tm, rt_stats* stats) {
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, size_t(D + 2) * CNT_TOTAL * sizeof(unsigned long long), st));
+    const bool shadows = s->n_lights > 0;
+    std::vector<long long> count(size_t(D) + 1, 0);  // sync walk: exact ray count of each level
+    int last = D;
     long long n = n0;
-    for (int d = 0; n > 0; ++d) {
-        const int remaining = max_depth - d;
-        long long next_cap = 0;
-        if (remaining > 0) {
-            next_cap = 2 * n;
-            int rc = ensure_level(s, size_t(d) + 1, next_cap);
+    for (int d = 0; d <= D; ++d) {
+        const int remaining = D - d;
+        if (sync && remaining > 0) {
+            int rc = ensure_level(s, size_t(d) + 1, 2 * n);
             if (rc != RT_OK) return rc;
         }
         const Level& L = s->levels[size_t(d)].L;
         const Level& N = remaining > 0 ? s->levels[size_t(d) + 1].L : L;
-        HIP_TRY(hipMemsetAsync(s->d_counters + CNT_NEXT, 0, (CNT_TOTAL - CNT_NEXT) * sizeof(unsigned long long), st));
+        const Level& P = d > 0 ? s->levels[size_t(d) - 1].L : L;
+        const bool exact = d == 0 || sync;
+        const long long n_arg = exact ? n : s->levels[size_t(d)].cap;
+        const unsigned long long* n_dev = exact ? nullptr : counter_block(s, d - 1) + CNT_NEXT;
+        const long long next_cap = remaining > 0 ? s->levels[size_t(d) + 1].cap : 0;
+        unsigned long long* ctr = counter_block(s, d);
+        unsigned long long* prev = d > 0 && shadows ? counter_block(s, d - 1) : nullptr;
+        const long long prev_upper = d > 0 ? (sync ? count[size_t(d) - 1] : (d == 1 ? n0 : s->levels[size_t(d) - 1].cap)) : 0;
+        count[size_t(d)] = n_arg;
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        { int rc = counters ? launch_trace<true>(s, st, L, n, nullptr, remaining, s->d_counters) : launch_trace<false>(s, st, L, n, nullptr, remaining, s->d_counters); if (rc != RT_OK) return rc; }
+        { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
-        if (counters && stats) {  // instrumented run: split the work counters per kernel class
-            HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            for (int k = 0; k < RT_WORK_COUNT; ++k) {
-                stats->work_trace[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
-                work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
-            }
-        }
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        launch_queue(st, L, n, nullptr, next_cap, s->d_counters);
+        launch_queue(st, L, n_arg, n_dev, next_cap, ctr);
         tm.end();
-        const int want = (s->n_lights > 0 ? 1 : 0) | (s->any_transparent ? 2 : 0);
-        if (counters && stats) {  // instrumented run: one queue per launch, so that the work counters stay apart
-            for (int phase = 1; phase <= 2; phase <<= 1) {
-                if (!(want & phase)) continue;
-                tm.begin(phase == 1 ? &stats->ms_shadow : &stats->ms_collect);
-                { int rc = launch_secondary<true>(s, st, L, n, phase, s->d_counters); if (rc != RT_OK) return rc; }
-                tm.end();
-                if (phase == 1) stats->n_shadow_launches++;
-                HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                int64_t* dst = phase == 1 ? stats->work_shadow : stats->work_container;
-                for (int k = 0; k < RT_WORK_COUNT; ++k) {
-                    dst[k] += (int64_t)(s->h_counters[CNT_W_XFORMS + k] - work_prev[k]);
-                    work_prev[k] = s->h_counters[CNT_W_XFORMS + k];
-                }
-            }
-        } else if (want) {
-            tm.begin(stats ? &stats->ms_shadow : nullptr);
-            { int rc = counters ? launch_secondary<true>(s, st, L, n, want, s->d_counters) : launch_secondary<false>(s, st, L, n, want, s->d_counters); if (rc != RT_OK) return rc; }
+        if (s->any_transparent && (remaining > 0 || s->ds.walk_at_zero)) {
+            tm.begin(stats ? &stats->ms_collect : nullptr);
+            { int rc = launch_walk<COUNT>(s, st, L, n_arg, ctr); if (rc != RT_OK) return rc; }
             tm.end();
-            if (stats && (want & 1)) stats->n_shadow_launches++;
+            if (stats) stats->n_shadow_launches++;
         }
-        tm.begin(stats ? &stats->ms_shade : nullptr);
-        hipLaunchKernelGGL(k_finish, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, L, N, n, (const unsigned long long*)nullptr, remaining);
-        tm.end();
+        if (remaining > 0) {
+            tm.begin(stats ? &stats->ms_shade : nullptr);
+            hipLaunchKernelGGL(k_spawn, dim3(blocks_for(n_arg)), dim3(BLOCK), 0, st, L, N, n_arg, n_dev);
+            tm.end();
+        }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        counts.push_back(n);
-        total_shaded += (long long)s->h_counters[CNT_SHADOW_Q];
-        total_walks += (long long)s->h_counters[CNT_CONTAINER_Q];
-        long long next = (long long)s->h_counters[CNT_NEXT];
-        if (next > next_cap) {
-            rt_set_error("internal: level %d spawned %lld rays into a queue of %lld", d, next, next_cap);
-            return RT_ERR_OVERFLOW;
+        if (sync) {
+            HIP_TRY(hipMemcpyAsync(s->h_counters + size_t(d) * CNT_COUNT, ctr, CNT_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const long long next = (long long)s->h_counters[size_t(d) * CNT_COUNT + CNT_NEXT];
+            if (next > next_cap) {
+                rt_set_error("internal: level %d spawned %lld rays into a queue of %lld", d, next, next_cap);
+                return RT_ERR_OVERFLOW;
+            }
+            n = next;
+            if (n == 0) { last = d; break; }
         }
-        n = next;
+    }
+    if (shadows) {  // the shadow rays of the last level that holds rays: a k_trace launch without a closest-hit part
+        const Level& P = s->levels[size_t(last)].L;
+        tm.begin(stats ? &stats->ms_trace : nullptr);
+        { int rc = launch_trace<COUNT>(s, st, P, 0, nullptr, 0, counter_block(s, last + 1), P, counter_block(s, last), count[size_t(last)]); if (rc != RT_OK) return rc; }
+        tm.end();
+        if (stats) stats->n_trace_launches++;
     }
     tm.begin(stats ? &stats->ms_resolve : nullptr);
-    for (int d = int(counts.size()) - 1; d >= 0; --d) {
-        bool has_next = d + 1 < int(counts.size());
+    for (int d = last; d >= 0; --d) {
         const Level& L = s->levels[size_t(d)].L;
-        const Level& N = has_next ? s->levels[size_t(d) + 1].L : L;
-        hipLaunchKernelGGL(k_resolve, dim3(blocks_for(counts[size_t(d)])), dim3(BLOCK), 0, st, L, N, counts[size_t(d)],
-                           (const unsigned long long*)nullptr, has_next ? 1 : 0);
+        const Level& N = d < last ? s->levels[size_t(d) + 1].L : L;
+        const bool exact = d == 0 || sync;
+        const unsigned long long* n_dev = exact ? nullptr : counter_block(s, d - 1) + CNT_NEXT;
+        hipLaunchKernelGGL(k_shade, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev, d < last ? 1 : 0);
     }
     tm.end();
     HIP_TRY(hipGetLastError());
-    // give the levels this frame did not reach a (small) queue too, so that the next frame can be enqueued in one go
-    for (int d = int(counts.size()); d <= max_depth && d < ASYNC_LEVELS; ++d) {
-        int rc = ensure_level(s, size_t(d), 64);
+    // one strided copy: the CNT_COUNT plain counters of every block
+    HIP_TRY(hipMemcpy2DAsync(s->h_counters, CNT_COUNT * sizeof(unsigned long long), s->d_counters, CNT_TOTAL * sizeof(unsigned long long),
+                             CNT_COUNT * sizeof(unsigned long long), size_t(D + 2), hipMemcpyDeviceToHost, st));
+    if (sync) {
+        // give the levels this frame did not reach a (small) queue too, so that the next frame can be enqueued in one go
+        for (int d = last + 1; d <= D; ++d) {
+            int rc = ensure_level(s, size_t(d), 64);
+            if (rc != RT_OK) return rc;
+        }
+    }
+    return RT_OK;
+}
+
+// after the stream has been waited for: ray accounting and work counters out of the counter blocks
+void fill_stats(rt_scene* s, int D, rt_stats* stats) {
+    if (!stats) return;
+    int64_t shaded = 0, walks = 0, refl = 0, refr = 0, tir = 0;
+    int levels = 1;
+    for (int d = 0; d <= D + 1; ++d) {
+        const unsigned long long* c = s->h_counters + size_t(d) * CNT_COUNT;
+        refl += (int64_t)c[CNT_REFLECT];
+        refr += (int64_t)c[CNT_REFRACT];
+        tir += (int64_t)c[CNT_TIR];
+        shaded += (int64_t)c[CNT_SHADOW_Q];
+        walks += (int64_t)c[CNT_CONTAINER_Q];
+        if (d < D && c[CNT_NEXT] > 0) levels = d + 2;
+        for (int k = 0; k < RT_WORK_COUNT; ++k) {
+            stats->work_trace[k] += (int64_t)c[CNT_W_XFORMS + k];
+            stats->work_shadow[k] += (int64_t)c[CNT_WS_XFORMS + k];
+            stats->work_container[k] += (int64_t)c[CNT_WC_XFORMS + k];
+        }
+    }
+    stats->rays_reflect = refl;
+    stats->rays_refract = refr - tir;
+    stats->shaded_nodes = shaded;
+    stats->rays_shadow = shaded * s->n_lights;
+    stats->rays_container = walks;
+    stats->levels = levels;
+}
+
+int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats) {
+    return counters ? enqueue_levels<true>(s, st, n0, D, sync, tm, stats) : enqueue_levels<false>(s, st, n0, D, sync, tm, stats);
+}
+
+// color_at for every ray already sitting in level 0 (n0 slots), complete when it returns: the whole tree enqueued at
+// once when the queues exist, else (or when one overflowed) the level-by-level walk that sizes them.
+int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, rt_stats* stats) {
+    if (D < 0) D = 0;  // color_at with remaining <= 0 still traces and shades the ray itself (src/world.rs:81-90)
+    int rc = ensure_counters(s, D + 2);
+    if (rc != RT_OK) return rc;
+    Timer tm{s, st, stats != nullptr};
+    if (levels_sized(s, D)) {
+        rc = enqueue_levels_any(s, st, n0, D, false, counters, tm, stats);
         if (rc != RT_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!levels_overflowed(s, D)) {
+            tm.collect();
+            fill_stats(s, D, stats);
+            return RT_OK;
+        }
+        if (stats) {  // start the accounting over
+            const int64_t primary = stats->rays_primary;
+            const double raygen = stats->ms_raygen;
+            std::memset(stats, 0, sizeof *stats);
+            stats->rays_primary = primary;
+            stats->ms_raygen = raygen;
+        }
+        tm.pairs.clear();
+        tm.used = 0;
     }
-    if (stats) {
-        const unsigned long long* c = s->h_counters;
-        stats->rays_reflect = (int64_t)c[CNT_REFLECT];
-        stats->rays_refract = (int64_t)c[CNT_REFRACT] - (int64_t)c[CNT_TIR];
-        stats->shaded_nodes = total_shaded;
-        stats->rays_shadow = total_shaded * s->n_lights;
-        stats->rays_container = total_walks;
-        stats->levels = int32_t(counts.size());
-    }
+    rc = enqueue_levels_any(s, st, n0, D, true, counters, tm, stats);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.collect();
+    fill_stats(s, D, stats);
     return RT_OK;
 }
 
@@ -520,6 +532,7 @@ int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams
     return RT_OK;
 }
 
+// Camera::render for one shard, all work ordered on `st`, complete (the host has waited) when it returns.
 int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb,
                       int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots, bool frame = false) {
     long long n_valid = 0;
@@ -530,124 +543,76 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         stats->rays_primary = n_valid;
     }
     if (n_slots == 0) return RT_OK;
-    // ---- several sub-frame chains in flight (only the plain path: no stats, no instrumentation)
-    // measured per shard size on the 1080p frame: 259k slots 1.09 ms with one chain / 1.17 with two, 518k 1.28 / 1.22
-    const int K = int(std::min<long long>(s->max_chains, std::max<long long>(1, n_slots / 256000)));
-    if (!stats && !opts->want_counters) {
-        const int D = opts->max_depth;
-        CameraParams ck[rt_scene::MAX_CHAINS];
-        long long nk[rt_scene::MAX_CHAINS] = {0, 0, 0, 0};
-        bool all_sized = true;
-        for (int k = 0; k < K; ++k) {
-            long long nv = 0;
-            rc = camera_params(cam, opts->rank + k * opts->n_ranks, opts->n_ranks * K, ck[k], nk[k], nv);
-            if (rc != RT_OK) return rc;
-            if (nk[k] == 0) continue;
-            ChainScope scope(s, k);
-            rc = ensure_level(s, 0, nk[k]);
-            if (rc != RT_OK) return rc;
-            all_sized = all_sized && levels_sized_for_async(s, D, false, nullptr);
-        }
-        // everything a captured frame bakes in
+    const int D = opts->max_depth < 0 ? 0 : opts->max_depth;
+    if ((rc = ensure_level(s, 0, n_slots)) != RT_OK || (rc = ensure_counters(s, D + 2)) != RT_OK) return rc;
+    auto raygen = [&]() { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots); };
+    auto output = [&]() {
+        hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
+    };
+    // ---- the plain path (no statistics): the whole frame replayed as one HIP graph while nothing it bakes in changes
+    if (!stats && !opts->want_counters && s->use_graph && levels_sized(s, D)) {
         std::string key;
         auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
         put(cam, sizeof *cam); put(&opts->rank, sizeof opts->rank); put(&opts->n_ranks, sizeof opts->n_ranks);
-        put(&D, sizeof D); put(&K, sizeof K); put(&d_rgb, sizeof d_rgb); put(&d_id, sizeof d_id); put(&d_flags, sizeof d_flags);
-        put(&st, sizeof st); put(&frame, sizeof frame);
-        for (int k = 0; k < K; ++k) {
-            ChainScope scope(s, k);
-            for (int d = 0; d <= D && size_t(d) < s->levels.size(); ++d) { put(&s->levels[size_t(d)].block, sizeof(void*)); put(&s->levels[size_t(d)].cap, sizeof(long long)); }
-        }
-        // chain k's whole frame on stream sk (plain enqueue, or recorded while `st` is capturing)
-        auto enqueue_chain = [&](int k) -> int {
-            ChainScope scope(s, k);
-            hipStream_t sk = s->parked[k].stream;
-            HIP_TRY(hipStreamWaitEvent(sk, s->ev_in, 0));
-            hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, ck[k], s->levels[0].L, nk[k]);
-            int rc2 = enqueue_levels_async(s, sk, nk[k], D);
-            if (rc2 != RT_OK) return rc2;
-            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, sk, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k, ck[k], frame ? 1 : 0);
-            HIP_TRY(hipEventRecord(s->parked[k].done, sk));
-            return RT_OK;
-        };
-        bool ran_async = false;
-        if (all_sized && s->use_graph) {
-            if (!s->graph_exec || key != s->graph_key) {
-                if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
-                hipGraph_t graph = nullptr;
-                HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                int rcc = RT_OK;
-                if (hipEventRecord(s->ev_in, st) != hipSuccess) rcc = RT_ERR_HIP;
-                for (int k = 0; k < K && rcc == RT_OK; ++k)
-                    if (nk[k]) {
-                        rcc = enqueue_chain(k);
-                        if (rcc == RT_OK && hipStreamWaitEvent(st, s->parked[k].done, 0) != hipSuccess) rcc = RT_ERR_HIP;
-                    }
+        put(&D, sizeof D); put(&d_rgb, sizeof d_rgb); put(&d_id, sizeof d_id); put(&d_flags, sizeof d_flags);
+        put(&st, sizeof st); put(&frame, sizeof frame); put(&s->d_counters, sizeof s->d_counters);
+        for (int d = 0; d <= D; ++d) { put(&s->levels[size_t(d)].block, sizeof(void*)); put(&s->levels[size_t(d)].cap, sizeof(long long)); }
+        if (!s->graph_exec || key != s->graph_key) {
+            if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            // a stream that cannot capture (it is being captured by the caller, or capture is unavailable) is not an
+            // error: the frame is simply enqueued launch by launch
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                Timer off{s, st, false};
+                raygen();
+                int rcc = enqueue_levels<false>(s, st, n_slots, D, false, off, nullptr);
+                output();
                 hipError_t ee = hipStreamEndCapture(st, &graph);
                 if (rcc != RT_OK || ee != hipSuccess || !graph) {
                     if (graph) (void)hipGraphDestroy(graph);
                     (void)hipGetLastError();
-                    s->use_graph = false;  // capture is not available here: plain enqueue from now on
+                    s->use_graph = false;
                 } else {
                     hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
                     (void)hipGraphDestroy(graph);
                     if (ei != hipSuccess) { s->graph_exec = nullptr; (void)hipGetLastError(); s->use_graph = false; }
                     else s->graph_key = key;
                 }
-            }
-            if (s->graph_exec) {
-                HIP_TRY(hipGraphLaunch(s->graph_exec, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                ran_async = true;
+            } else {
+                (void)hipGetLastError();
+                s->use_graph = false;
             }
         }
-        bool enqueued[rt_scene::MAX_CHAINS] = {false, false, false, false};
-        if (ran_async) {
-            for (int k = 0; k < K; ++k) enqueued[k] = nk[k] != 0;
-        } else {
-            HIP_TRY(hipEventRecord(s->ev_in, st));
-            for (int k = 0; k < K; ++k) {
-                if (nk[k] == 0) continue;
-                bool sized;
-                { ChainScope scope(s, k); sized = levels_sized_for_async(s, D, false, nullptr); }
-                if (!sized) continue;
-                rc = enqueue_chain(k);
-                if (rc != RT_OK) return rc;
-                enqueued[k] = true;
-            }
-            HIP_TRY(hipGetLastError());
-            for (int k = 0; k < K; ++k)
-                if (enqueued[k]) HIP_TRY(hipEventSynchronize(s->parked[k].done));
-        }
-        for (int k = 0; k < K; ++k) {
-            if (nk[k] == 0) continue;
-            ChainScope scope(s, k);
-            if (enqueued[k] && !levels_async_overflowed(s, D)) continue;
-            // first frame of this chain, or a queue overflowed: level-by-level walk (sizes the queues), on the caller's stream
-            hipLaunchKernelGGL(k_raygen, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, ck[k], s->levels[0].L, nk[k]);
-            rc = run_levels(s, st, nk[k], D, false, nullptr);
+        if (s->graph_exec) {
+            HIP_TRY(hipGraphLaunch(s->graph_exec, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (!levels_overflowed(s, D)) return RT_OK;
+            // the view changed and a queue overflowed: the level-by-level walk below grows the queues (and the next
+            // frame captures a new graph, its key holds the queue blocks)
+            raygen();
+            Timer off{s, st, false};
+            rc = enqueue_levels<false>(s, st, n_slots, D, true, off, nullptr);
             if (rc != RT_OK) return rc;
-            hipLaunchKernelGGL(k_output, dim3(blocks_for(nk[k])), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, nk[k], d_rgb, d_id, d_flags, K, k, ck[k], frame ? 1 : 0);
+            output();
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));
+            return RT_OK;
         }
-        return RT_OK;
     }
     EventPair whole;
     if (stats) {
         HIP_TRY(hipEventCreate(&whole.e0));
         HIP_TRY(hipEventCreate(&whole.e1));
         HIP_TRY(hipEventRecord(whole.e0, st));
+        HIP_TRY(hipEventCreate(&whole.r0));
+        HIP_TRY(hipEventCreate(&whole.r1));
+        HIP_TRY(hipEventRecord(whole.r0, st));
     }
-    rc = ensure_level(s, 0, n_slots);
+    raygen();
+    if (stats) HIP_TRY(hipEventRecord(whole.r1, st));
+    rc = run_levels(s, st, n_slots, D, opts->want_counters != 0, stats);
     if (rc != RT_OK) return rc;
-    Timer tm{s, st, stats != nullptr};
-    tm.begin(stats ? &stats->ms_raygen : nullptr);
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots);
-    tm.end();
-    rc = run_levels(s, st, n_slots, opts->max_depth, opts->want_counters != 0, stats);
-    if (rc != RT_OK) return rc;
-    hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
+    output();
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(whole.e1, st));
@@ -655,6 +620,10 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, whole.e0, whole.e1));
         stats->ms_total = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, whole.r0, whole.r1));
+        stats->ms_raygen = ms;
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));
     }
     return RT_OK;
 }
@@ -800,24 +769,12 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         double tr = mp[RT_MAT_TRANSPARENCY], rf = mp[RT_MAT_REFLECTIVE];
         if (!(std::fabs(tr - 0.) < EPS) || (rf > 0. && tr > 0.)) s->any_transparent = true;
     }
-    if (hipStreamCreate(&s->stream) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&s->d_counters), size_t(ASYNC_LEVELS) * CNT_TOTAL * sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), size_t(ASYNC_LEVELS) * CNT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-        hipEventCreate(&s->ev[0]) != hipSuccess || hipEventCreate(&s->ev[1]) != hipSuccess) {
-        rt_set_error("could not create stream / counters: %s", hipGetErrorString(hipGetLastError()));
+    if (hipStreamCreate(&s->stream) != hipSuccess) {
+        rt_set_error("could not create the scene's stream: %s", hipGetErrorString(hipGetLastError()));
         return fail(RT_ERR_HIP);
     }
-    if (hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_HIP); }
-    for (int k = 0; k < rt_scene::MAX_CHAINS; ++k) {
-        rt_scene::Parked& p = s->parked[k];
-        bool ok = hipStreamCreate(&p.stream) == hipSuccess && hipEventCreateWithFlags(&p.done, hipEventDisableTiming) == hipSuccess;
-        if (ok && k > 0)
-            ok = hipMalloc(reinterpret_cast<void**>(&p.spill), size_t(BVH_STACK - LDS_STACK) * size_t(s->ds.spill_lanes) * sizeof(int32_t)) == hipSuccess &&
-                 hipMalloc(reinterpret_cast<void**>(&p.d_counters), size_t(ASYNC_LEVELS) * CNT_TOTAL * sizeof(unsigned long long)) == hipSuccess &&
-                 hipHostMalloc(reinterpret_cast<void**>(&p.h_counters), size_t(ASYNC_LEVELS) * CNT_COUNT * sizeof(unsigned long long)) == hipSuccess;
-        if (!ok) { rt_set_error("could not create chain %d: %s", k, hipGetErrorString(hipGetLastError())); return fail(RT_ERR_HIP); }
-    }
+    if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
     if (const char* e = std::getenv("RT_AMD_GRAPH")) s->use_graph = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_AMD_CHAINS")) s->max_chains = std::min(std::max(std::atoi(e), 1), int(rt_scene::MAX_CHAINS));
     *out = s;
     return RT_OK;
 }
@@ -829,25 +786,13 @@ void rt_scene_destroy(rt_scene* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     for (LevelStore& l : s->levels)
         if (l.block) (void)hipFree(l.block);
-    for (rt_scene::Parked& p : s->parked) {
-        if (p.stream) (void)hipStreamSynchronize(p.stream);
-        for (LevelStore& l : p.levels)
-            if (l.block) (void)hipFree(l.block);
-        if (p.d_counters) (void)hipFree(p.d_counters);
-        if (p.h_counters) (void)hipHostFree(p.h_counters);
-        if (p.spill) (void)hipFree(p.spill);
-        if (p.done) (void)hipEventDestroy(p.done);
-        if (p.stream) (void)hipStreamDestroy(p.stream);
-    }
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (GrowBuf* b : {&s->out_rgb, &s->out_id, &s->out_flags, &s->frame_rgb, &s->frame_id, &s->frame_flags, &s->in_a, &s->in_b,
                        &s->misc_a, &s->misc_b, &s->misc_c})
         if (b->p) (void)hipFree(b->p);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
-    if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
-    if (s->ev[1]) (void)hipEventDestroy(s->ev[1]);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

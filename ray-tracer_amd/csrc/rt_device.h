@@ -85,48 +85,37 @@ struct Level {
     double *ox, *oy, *oz, *dx, *dy, *dz;  // ray (origin.x is NaN for a padding slot)
     double *ht, *hu, *hv;                 // hit t and the (u,v) normal_at must use (F5)
     int32_t* hkey;                        // node*4 + push index of the hit, -1 = miss
-    double *sr, *sg, *sb;                 // surface colour (sum of Material::lighting over lights)
-    double *k_refl, *k_transp, *k_schlick;  // material.reflective, material.transparency, reflectance
-    int32_t* mode;                        // 1 = Schlick blend (reflective > 0 && transparency > 0)
+    double *px, *py, *pz, *nx, *ny, *nz;  // world-space point / normal of the hit (prepare_computations), k_trace -> k_shade
+    int32_t* mode;                        // stage bits ST_* (rt_kernels.hip.h)
     int32_t *child_refl, *child_refr;     // index in the next level or -1 (=> BLACK)
     double *cr, *cg, *cb;                 // resolved colour of this node
     uint8_t* flags;                       // RT_FLAG_* per ray
     uint32_t* flags32;                    // the same bytes, for atomicOr from the queue stages
-    // between k_prepare and k_finish: world-space point / normal of the hit (aliases of sr..k_schlick)
-    double *px, *py, *pz, *nx, *ny, *nz;
-    int32_t* shadow_q;                    // ray indices queued for k_shadow
-    int32_t* cont_q;                      // ray indices queued for k_container
+    int32_t* shadow_q;                    // ray indices whose shadow rays the next k_trace launch traces
+    int32_t* cont_q;                      // ray indices queued for k_walk
     uint8_t* shadowed;                    // [ray][light]
 };
 
-// Device counters (one int64 each).
+// Device counters (one int64 each).  A frame uses one block of CNT_TOTAL counters per recursion level (plus one for
+// the launch after the last level), all zeroed when the frame starts.
 enum Counter : int {
     CNT_REFLECT = 0,   // reflection rays spawned
     CNT_REFRACT,       // refraction rays spawned
-    CNT_SHADED,        // nodes that hit something
-    CNT_CONTAINER,     // container-walk list passes
     CNT_TIR,           // refraction slots reserved by k_queue that total internal reflection left dead
-    CNT_W_XFORMS,
-    CNT_W_BOX,
-    CNT_W_GATE,
-    CNT_W_TRI,
-    CNT_W_TRI_DET,
-    CNT_W_TRI_U,
-    CNT_W_TRI_V,
-    CNT_W_PRIM0,       // +0..4: sphere, plane, cube, cylinder, cone
-    CNT_W_BVH_NODES = CNT_W_PRIM0 + 5,
-    // ---- zeroed together before every level (one memset from CNT_NEXT to CNT_TOTAL)
     CNT_NEXT,          // rays appended to the next level
-    CNT_SHADOW_Q,      // entries of the level's shadow queue
-    CNT_CONTAINER_Q,   // entries of the level's container queue
-    CNT_COUNT,         // what the host reads back
+    CNT_SHADOW_Q,      // entries of the level's shadow queue (= nodes that hit something)
+    CNT_CONTAINER_Q,   // entries of the level's container queue (n1/n2 walks)
+    // work of the instrumented build (rt_render_opts.want_counters), RT_WORK_COUNT rows per kernel class
+    CNT_W_XFORMS,                                    // closest-hit part of k_trace for this level's rays
+    CNT_WS_XFORMS = CNT_W_XFORMS + RT_WORK_COUNT,    // shadow rays of THIS level's hits (traced by the next k_trace)
+    CNT_WC_XFORMS = CNT_WS_XFORMS + RT_WORK_COUNT,   // k_walk
+    CNT_COUNT = CNT_WC_XFORMS + RT_WORK_COUNT,       // what the host reads back
     // chunk feeds of the persistent traversal kernels: FEED_PARTS counters per kernel, FEED_STRIDE apart
-    CNT_FEED_TRACE = 32,
+    CNT_FEED_TRACE = 64,
     CNT_FEED_SHADOW = CNT_FEED_TRACE + FEED_PARTS * FEED_STRIDE,
     CNT_FEED_CONTAINER = CNT_FEED_SHADOW + FEED_PARTS * FEED_STRIDE,
     CNT_TOTAL = CNT_FEED_CONTAINER + FEED_PARTS * FEED_STRIDE
 };
-static_assert(CNT_W_BVH_NODES - CNT_W_XFORMS + 1 == RT_WORK_COUNT, "work counter rows must match rt_abi.h");
 static_assert(CNT_COUNT <= CNT_FEED_TRACE, "feed counters overlap the plain ones");
 
 struct CameraParams {

@@ -6,12 +6,15 @@
 // become fmax/fmin (both ignore a NaN operand).  Tuples drop w on the device: rt_scene_create only accepts affine
 // inverses, for which w stays exactly 1 (points) or 0 (vectors) and its terms add exactly 0.0.
 //
-// Execution model: one ray per lane.  A frame is a wavefront pipeline over recursion levels:
-// k_trace(level) -> k_queue(level) -> k_secondary(level) -> k_finish(level) ... then k_resolve(level) from the deepest
-// level up, which evaluates shade_hit's blend in the reference's own order (src/world.rs:68-78) so colours match the
-// recursive form bit for bit.  Traversal kernels (k_trace, k_secondary, k_list, k_shadow_points) are persistent
-// 1024-lane workgroups, one per CU, fed 64-ray chunks per wavefront; the rest are plain streaming kernels.
-// DESIGN.md section 4 has the why and the measurements.
+// Execution model: one ray per lane.  A frame is a wavefront pipeline over recursion levels d = 0..D:
+//   k_trace(d)  closest hits of level d + prepare_computations, AND the shadow rays of level d-1 in the same launch
+//   k_queue(d)  stream compaction: shadow queue, n1/n2-walk queue, child slots in level d+1
+//   k_walk(d)   n1/n2 container walks (transparent hits only)      k_spawn(d)  reflection / refraction rays of level d+1
+// then one more k_trace for the shadow rays of the last level, and k_shade(d) from the deepest level up: lighting,
+// schlick and shade_hit's blend in the reference's own order (src/world.rs:57-79), so colours match the recursive form
+// bit for bit.  Traversal kernels (k_trace, k_walk, k_list, k_shadow_points) are persistent 1024-lane workgroups, one
+// per CU, fed 64-ray chunks per wavefront; the rest are plain streaming kernels.  DESIGN.md section 4 has the why and
+// the measurements.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -899,13 +902,14 @@ __device__ __forceinline__ TravMem trav_setup(const DScene& S, Feed& feed, unsig
 // ---------------------------------------------------------------------------------------------------------
 // Wave-level helpers.
 
+// `counters`: the first of the RT_WORK_COUNT words of one work set (CNT_W_XFORMS, CNT_WS_XFORMS or CNT_WC_XFORMS)
 __device__ __forceinline__ void flush_work(const Work& w, unsigned long long* __restrict__ counters) {
     const unsigned* p = reinterpret_cast<const unsigned*>(&w);
     constexpr int N = sizeof(Work) / sizeof(unsigned);
     for (int k = 0; k < N; ++k) {
         unsigned v = p[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counters + CNT_W_XFORMS + k, (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(counters + k, (unsigned long long)v);
     }
 }
 
@@ -1261,18 +1265,9 @@ __device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One recursion level = four launches:
-//   k_trace      closest hit (intersect_world + Intersection::hit) and, in the same lane while ray and hit are in
-//                registers, prepare_computations (point, normal chain, inside flip) + the per-ray stage bits
-//   k_queue      pure stream compaction over the stage bits: shadow queue, container queue and the slots of the
-//                reflection / refraction rays in level d+1 (tile-counted, a handful of atomics per 8192 rays)
-//   k_secondary  World::is_shadowed for every queued (hit, light) and the n1/n2 walk for every queued transparent hit
-//   k_finish     Material::lighting over the lights, reflected_color / refracted_color ray spawn into the slots,
-//                node record; one ray per lane, no atomics, no barriers
-// Between k_trace and k_finish the world-space point and normal live in the (not yet written) surface / coefficient
-// columns of the level, and n1/n2 in the hit-u/v columns.
-//
-// Stage bits (Level::mode until k_finish overwrites it with the Schlick flag):
+// Stage bits (Level::mode), written by k_trace for every ray of a level and read by k_queue, k_walk, k_spawn, k_shade.
+// Between k_trace and k_shade the world-space point and normal of the hit live in the px..nz columns, and — once
+// prepare_computations has consumed the hit's u,v — n1/n2 in the hit-u/v columns.
 constexpr int ST_HIT = 1;        // the ray hit something: shade it
 constexpr int ST_WALK = 2;       // prepare_computations' n1/n2 are observable for this hit: run the container walk
 constexpr int ST_REFLECT = 4;    // reflected_color spawns a ray (src/world.rs:110)
@@ -1286,7 +1281,7 @@ __device__ __forceinline__ bool needs_walk(const DScene& S, double reflective, d
     // refracted_color and reflected_color return BLACK before using them (src/world.rs:110,121) and schlick's result
     // only scales those two BLACKs: any FINITE reflectance gives surface + 0 + 0.  It is finite whenever every
     // refractive index in the scene is finite and positive and every leaf is equal to itself (F14: one that is not
-    // leaves n1 = n2 = 0 and schlick = NaN) — S.walk_at_zero == 0 — so the walk is skipped there and k_finish records
+    // leaves n1 = n2 = 0 and schlick = NaN) — S.walk_at_zero == 0 — so the walk is skipped there and k_shade uses
     // reflectance 0.
     if (remaining <= 0 && !S.walk_at_zero) return false;
     return !near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.);
@@ -1300,14 +1295,29 @@ __device__ __forceinline__ long long level_count(long long n, const unsigned lon
     return v < n ? v : n;
 }
 
-// `remaining` is the value color_at was called with at this level.
+// over_point / under_point exactly as prepare_computations forms them (src/intersection.rs:50-51)
+__device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(point, vmul(normal, EPS)); }
+__device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
+
+// One launch = the closest-hit pass of level d (rays of L, `remaining` is the value color_at was called with at this
+// level) AND the shadow rays of level d-1 (hits of P, queued by k_queue(d-1) in `prev_counters`' block).  is_shadowed
+// feeds only Material::lighting (src/world.rs:57-66), which nothing downstream of the ray tree waits for: the rays of
+// level d need prepare_computations and the n1/n2 walk of level d-1, never its shadows.  So the shadow rays ride along
+// with the next level's closest-hit pass instead of having a launch of their own: a traversal launch lasts as long as
+// its slowest 64-ray chunk (60-90 us whatever the ray count), and this way a frame pays that once per level, not
+// twice.  Either part may be empty (n_cap == 0: shadow rays only — the launch after the last level; prev_counters ==
+// null: level 0).  Every wavefront alternates between the two chunk feeds until both are dry.
 template <int SC, bool NEED_FIRST, bool COUNT>
 __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
-                                                  unsigned long long* counters) {
-    const long long n = level_count(n_cap, n_dev);
-    Feed feed;
+                                                  unsigned long long* counters, Level P, unsigned long long* prev_counters) {
+    const long long n = n_cap > 0 ? level_count(n_cap, n_dev) : 0;
+    const long long n_shadow = prev_counters ? (long long)prev_counters[CNT_SHADOW_Q] * S.n_lights : 0;
+    if (n == 0 && n_shadow == 0) return;  // uniform over the grid: nothing staged, nothing fed
+    Feed feed, shadow_feed;
+    __shared__ FeedShared shadow_shared;
+    shadow_feed.init(prev_counters ? prev_counters + CNT_FEED_SHADOW : nullptr, (n_shadow + 63) / 64, (RT_LDS FeedShared*)&shadow_shared);
     const TravMem M = trav_setup(S, feed, counters + CNT_FEED_TRACE, (n + 63) / 64);
-    Work w = {};
+    Work w = {}, ws = {};
     // A chunk's rays are requested one chunk ahead (just before the previous chunk's epilogue, whose dependent look-ups
     // they overlap): a wavefront is one of four on its SIMD, so nothing else hides that round trip.
     auto fetch = [&](long long c, V3& o, V3& d) {
@@ -1320,60 +1330,85 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long lon
         }
     };
     long long c = feed.next();
+    long long cs = shadow_feed.next();
     V3 o, d;
     fetch(c, o, d);
-    while (c >= 0) {
-        const long long i = c * 64 + (threadIdx.x & 63);
-        const bool alive = !is_dead_ray(o.x);
-        if (!alive) o = mk(0., 0., 0.);
-        ClosestSink<NEED_FIRST> sink;
-        sink.init(INFINITY);
-        traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
-        const long long c_next = feed.next();
-        V3 o_next, d_next;
-        fetch(c_next, o_next, d_next);
-        // ---- epilogue: prepare_computations (src/intersection.rs:38-48) for the lanes that hit something
-        const int key = alive ? sink.best_key : -1;
-        const bool hit = key >= 0;
-        const int node = hit ? key >> 2 : 0;
-        NodeRec rec = {0, 0, 0, 0};
-        if (hit) rec = S.node_rec[node];
-        double reflective = 0., transparency = 0.;
-        if (hit) {
-            const double* __restrict__ m = S.mat + (size_t)rec.material * RT_MAT_STRIDE;
-            reflective = m[RT_MAT_REFLECTIVE];
-            transparency = m[RT_MAT_TRANSPARENCY];
+    while (c >= 0 || cs >= 0) {
+        if (c >= 0) {
+            const long long i = c * 64 + (threadIdx.x & 63);
+            const bool alive = !is_dead_ray(o.x);
+            if (!alive) o = mk(0., 0., 0.);
+            ClosestSink<NEED_FIRST> sink;
+            sink.init(INFINITY);
+            traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
+            const long long c_next = feed.next();
+            V3 o_next, d_next;
+            fetch(c_next, o_next, d_next);
+            // ---- epilogue: prepare_computations (src/intersection.rs:38-48) for the lanes that hit something
+            const int key = alive ? sink.best_key : -1;
+            const bool hit = key >= 0;
+            const int node = hit ? key >> 2 : 0;
+            NodeRec rec = {0, 0, 0, 0};
+            if (hit) rec = S.node_rec[node];
+            double reflective = 0., transparency = 0.;
+            if (hit) {
+                const double* __restrict__ m = S.mat + (size_t)rec.material * RT_MAT_STRIDE;
+                reflective = m[RT_MAT_REFLECTIVE];
+                transparency = m[RT_MAT_TRANSPARENCY];
+            }
+            double u = sink.bu, v = sink.bv;
+            unsigned flags = alive ? sink.flags : 0;  // a NaN t panics the reference's sort whether or not anything is hit
+            if (NEED_FIRST && hit && rec.kind == RT_SMOOTH_TRIANGLE) {
+                if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+                else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+            }
+            const V3 point = vadd(o, vmul(d, sink.best_t));  // Ray::position
+            V3 normal_vector = normal_at_wave(S, hit, rec, point, u, v);
+            int stage = 0;
+            if (hit) {
+                const V3 eye_vector = vneg(d);
+                if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
+                L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
+                L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
+                L.ht[i] = sink.best_t;
+                stage = ST_HIT;
+                if (needs_walk(S, reflective, transparency, remaining)) stage |= ST_WALK;
+                if (!(near_eq(reflective, 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
+                if (!(near_eq(transparency, 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
+            }
+            if (i < n) {
+                L.hkey[i] = key;
+                L.mode[i] = stage;
+                L.flags[i] = (uint8_t)flags;
+            }
+            c = c_next;
+            o = o_next;
+            d = d_next;
         }
-        double u = sink.bu, v = sink.bv;
-        unsigned flags = alive ? sink.flags : 0;  // a NaN t panics the reference's sort whether or not anything is hit
-        if (NEED_FIRST && hit && rec.kind == RT_SMOOTH_TRIANGLE) {
-            if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
-            else flags |= RT_FLAG_REF_PANIC_UV;                // reference would unwrap a None
+        if (cs >= 0) {  // World::is_shadowed for 64 (hit, light) pairs of the previous level
+            const long long j = cs * 64 + (threadIdx.x & 63);
+            const bool alive = j < n_shadow;
+            int light = 0;
+            long long i = 0;
+            V3 over_point = mk(0., 0., 0.);
+            if (alive) {
+                light = (int)(j % S.n_lights);
+                i = P.shadow_q[j / S.n_lights];
+                over_point = over_point_of(mk(P.px[i], P.py[i], P.pz[i]), mk(P.nx[i], P.ny[i], P.nz[i]));
+            }
+            unsigned flags = 0;
+            const bool sh = is_shadowed<SC, COUNT>(S, M, over_point, light, ws, flags, alive);
+            if (alive) {
+                P.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
+                if (flags) atomicOr(P.flags32 + (i >> 2), flags << (8 * (i & 3)));
+            }
+            cs = shadow_feed.next();
         }
-        const V3 point = vadd(o, vmul(d, sink.best_t));  // Ray::position
-        V3 normal_vector = normal_at_wave(S, hit, rec, point, u, v);
-        int stage = 0;
-        if (hit) {
-            const V3 eye_vector = vneg(d);
-            if (dot(normal_vector, eye_vector) < 0.) normal_vector = vneg(normal_vector);  // inside
-            L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
-            L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
-            L.ht[i] = sink.best_t;
-            stage = ST_HIT;
-            if (needs_walk(S, reflective, transparency, remaining)) stage |= ST_WALK;
-            if (!(near_eq(reflective, 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
-            if (!(near_eq(transparency, 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
-        }
-        if (i < n) {
-            L.hkey[i] = key;
-            L.mode[i] = stage;
-            L.flags[i] = (uint8_t)flags;
-        }
-        c = c_next;
-        o = o_next;
-        d = d_next;
     }
-    if (COUNT) flush_work(w, counters);
+    if (COUNT) {
+        flush_work(w, counters + CNT_W_XFORMS);
+        if (prev_counters) flush_work(ws, prev_counters + CNT_WS_XFORMS);
+    }
 }
 
 // Queue appends without an atomic per wavefront (returning atomics on one word are serialised in L2, 5-10 ns each
@@ -1470,105 +1505,70 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
     }
 }
 
-// over_point / under_point exactly as prepare_computations forms them (src/intersection.rs:50-51)
-__device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(point, vmul(normal, EPS)); }
-__device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
-
-// One launch serves both queues of a level (`phases` bit 0: shadow queue, bit 1: container queue; the instrumented
-// run launches them one at a time to keep their work counters apart).  The container chunks — few, and each one a
-// long latency-bound walk — go first, so that they overlap the bulk of the shadow chunks instead of forming a tail.
-template <int SC, bool COUNT, bool WALK>
-__global__ __launch_bounds__(TBLOCK, 4) void k_secondary(DScene S, Level L, unsigned long long* counters, int phases) {
-    const long long n_shadow = (phases & 1) ? (long long)counters[CNT_SHADOW_Q] * S.n_lights : 0;
-    const long long n_walk = (WALK && (phases & 2)) ? (long long)counters[CNT_CONTAINER_Q] : 0;
-    Feed shadow_feed, walk_feed;
-    __shared__ FeedShared walk_shared;
-    walk_feed.init(counters + CNT_FEED_CONTAINER, (n_walk + 63) / 64, (RT_LDS FeedShared*)&walk_shared);
-    const TravMem M = trav_setup(S, shadow_feed, counters + CNT_FEED_SHADOW, (n_shadow + 63) / 64);
+// The n1/n2 container walk of prepare_computations (src/intersection.rs:54-80) for every queued transparent hit of a
+// level, and with it the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_spawn
+// knows which refraction slots stay dead.  On the critical path of the ray tree (the refracted ray's direction needs
+// n1/n2), unlike the shadow rays, hence a launch of its own between k_queue and k_spawn.
+template <int SC, bool COUNT>
+__global__ __launch_bounds__(TBLOCK, 4) void k_walk(DScene S, Level L, unsigned long long* counters) {
+    const long long n_walk = (long long)counters[CNT_CONTAINER_Q];
+    if (n_walk == 0) return;
+    Feed walk_feed;
+    const TravMem M = trav_setup(S, walk_feed, counters + CNT_FEED_CONTAINER, (n_walk + 63) / 64);
     Work w = {};
-    if (WALK) {
-        for (long long c = walk_feed.next(); c >= 0; c = walk_feed.next()) {
-            const long long j = c * 64 + (threadIdx.x & 63);
-            const bool alive = j < n_walk;
-            long long i = 0;
-            V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-            double hit_t = 0.;
-            int hit_node = 0;
-            if (alive) {
-                i = L.cont_q[j];
-                o = mk(L.ox[i], L.oy[i], L.oz[i]);
-                d = mk(L.dx[i], L.dy[i], L.dz[i]);
-                hit_t = L.ht[i];
-                hit_node = L.hkey[i] >> 2;
-            }
-            unsigned flags = 0;
-            double n1, n2;
-            bool tir = false;
-            container_walk<SC, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
-            if (alive) {
-                L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
-                L.hv[i] = n2;
-                {   // the total-internal-reflection test of refracted_color (src/world.rs:125-130), so that k_finish
-                    // can count its spawns before it does its work
-                    V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-                    double n_ratio = n1 / n2;
-                    double cos_i = dot(eye_vector, normal_vector);
-                    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-                    tir = sin2_t > 1. && (L.mode[i] & ST_REFRACT);
-                    if (tir) L.mode[i] |= ST_TIR;
-                }
-                if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
-            }
-            const unsigned long long bt = __ballot(tir);  // refraction rays k_queue counted that will never fly
-            if (bt && (threadIdx.x & 63) == 0) atomicAdd(counters + CNT_TIR, (unsigned long long)__popcll(bt));
-        }
-    }
-    for (long long c = shadow_feed.next(); c >= 0; c = shadow_feed.next()) {
+    for (long long c = walk_feed.next(); c >= 0; c = walk_feed.next()) {
         const long long j = c * 64 + (threadIdx.x & 63);
-        const bool alive = j < n_shadow;
-        int light = 0;
+        const bool alive = j < n_walk;
         long long i = 0;
-        V3 over_point = mk(0., 0., 0.);
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        double hit_t = 0.;
+        int hit_node = 0;
         if (alive) {
-            light = (int)(j % S.n_lights);
-            i = L.shadow_q[j / S.n_lights];
-            over_point = over_point_of(mk(L.px[i], L.py[i], L.pz[i]), mk(L.nx[i], L.ny[i], L.nz[i]));
+            i = L.cont_q[j];
+            o = mk(L.ox[i], L.oy[i], L.oz[i]);
+            d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            hit_t = L.ht[i];
+            hit_node = L.hkey[i] >> 2;
         }
         unsigned flags = 0;
-        bool sh = is_shadowed<SC, COUNT>(S, M, over_point, light, w, flags, alive);
+        double n1, n2;
+        bool tir = false;
+        container_walk<SC, COUNT>(S, M, o, d, hit_t, hit_node, w, n1, n2, flags, alive);
         if (alive) {
-            L.shadowed[i * S.n_lights + light] = sh ? 1 : 0;
+            L.hu[i] = n1;  // prepare has consumed the hit's u,v: the columns now carry n1, n2
+            L.hv[i] = n2;
+            {
+                V3 eye_vector = vneg(d), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+                double n_ratio = n1 / n2;
+                double cos_i = dot(eye_vector, normal_vector);
+                double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+                tir = sin2_t > 1. && (L.mode[i] & ST_REFRACT);
+                if (tir) L.mode[i] |= ST_TIR;
+            }
             if (flags) atomicOr(L.flags32 + (i >> 2), flags << (8 * (i & 3)));
         }
+        const unsigned long long bt = __ballot(tir);  // refraction rays k_queue counted that will never fly
+        if (bt && (threadIdx.x & 63) == 0) atomicAdd(counters + CNT_TIR, (unsigned long long)__popcll(bt));
     }
-    if (COUNT) flush_work(w, counters);
+    if (COUNT) flush_work(w, counters + CNT_WC_XFORMS);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev,
-                                                  int remaining) {
+// reflected_color / refracted_color ray spawn (src/world.rs:109-137) into the slots k_queue reserved in the next
+// level.  One ray per lane, no atomics, no barriers.  Needs prepare_computations (k_trace) and, for a refraction
+// ray, the n1/n2 walk (k_walk) — not the shadow rays.
+__global__ __launch_bounds__(BLOCK) void k_spawn(Level L, Level N, long long n_cap, const unsigned long long* n_dev) {
     const long long n = level_count(n_cap, n_dev);
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const int stage = L.mode[i];
-    if (!(stage & ST_HIT)) return;
-    const int node = L.hkey[i] >> 2;
-    V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
-    V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-    V3 eye_vector = vneg(d);
-    V3 over_point = over_point_of(point, normal_vector);
-    const int mi = S.node_material[node];
-    const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
-    const int pat = S.mat_pattern[mi];
-    const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
-    const bool walked = stage & ST_WALK;
-    const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
-    // src/world.rs:57-66
-    V3 surface = mk(0., 0., 0.);
-    for (int l = 0; l < S.n_lights; ++l)
-        surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector, L.shadowed[i * S.n_lights + l] != 0));
+    if (!(stage & (ST_REFLECT | ST_REFRACT))) return;
     const int c0 = L.child_refl[i], c1 = L.child_refr[i];
+    if (c0 < 0 && c1 < 0) return;
+    const V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
+    const V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
     if (c0 >= 0) {  // reflected_color, src/world.rs:109-118
-        V3 refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
+        const V3 over_point = over_point_of(point, normal_vector);
+        const V3 refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
         N.ox[c0] = over_point.x; N.oy[c0] = over_point.y; N.oz[c0] = over_point.z;
         N.dx[c0] = refl_d.x; N.dy[c0] = refl_d.y; N.dz[c0] = refl_d.z;
     }
@@ -1577,6 +1577,9 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
             N.ox[c1] = dead_ray();
             L.child_refr[i] = -1;
         } else {  // refracted_color, src/world.rs:120-137
+            const bool walked = stage & ST_WALK;
+            const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
+            const V3 eye_vector = vneg(d);
             double n_ratio = n1 / n2;
             double cos_i = dot(eye_vector, normal_vector);
             double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
@@ -1587,40 +1590,50 @@ __global__ __launch_bounds__(BLOCK) void k_finish(DScene S, Level L, Level N, lo
             N.dx[c1] = refr_d.x; N.dy[c1] = refr_d.y; N.dz[c1] = refr_d.z;
         }
     }
-    int mode = (reflective > 0. && transparency > 0.) ? 1 : 0;
-    double reflectance = mode && walked ? schlick(eye_vector, normal_vector, n1, n2) : 0.;  // see needs_walk
-    // the point / normal columns are dead from here on: they become the node record
-    L.sr[i] = surface.x; L.sg[i] = surface.y; L.sb[i] = surface.z;
-    L.k_refl[i] = reflective;
-    L.k_transp[i] = transparency;
-    L.k_schlick[i] = reflectance;
-    L.mode[i] = mode;
 }
 
-// Kernel: bottom-up resolve of one level == the tail of shade_hit (src/world.rs:68-78) + color_at's miss case.
-__global__ __launch_bounds__(BLOCK) void k_resolve(Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next) {
+// Bottom-up: shade_hit for every node of one level (src/world.rs:57-79) == Material::lighting over the lights (the
+// shadow flags are in by now), schlick, and the blend with the children's resolved colours in the reference's own
+// operand order; color_at's miss case -> BLACK.  Surface colour, coefficients and reflectance never leave registers.
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next) {
     const long long n = level_count(n_cap, n_dev);
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    if (L.hkey[i] < 0) {  // miss -> BLACK
+    const int key = L.hkey[i];
+    if (key < 0) {  // miss -> BLACK
         L.cr[i] = 0.; L.cg[i] = 0.; L.cb[i] = 0.;
         return;
     }
-    V3 surface = mk(L.sr[i], L.sg[i], L.sb[i]);
+    const int stage = L.mode[i];
+    const int node = key >> 2;
+    const V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
+    const V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
+    const V3 eye_vector = vneg(d);
+    const V3 over_point = over_point_of(point, normal_vector);
+    const int mi = S.node_material[node];
+    const double* __restrict__ m = S.mat + (size_t)mi * RT_MAT_STRIDE;
+    const int pat = S.mat_pattern[mi];
+    const double reflective = m[RT_MAT_REFLECTIVE], transparency = m[RT_MAT_TRANSPARENCY];
+    const bool walked = stage & ST_WALK;
+    const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
+    // src/world.rs:57-66
+    V3 surface = mk(0., 0., 0.);
+    for (int l = 0; l < S.n_lights; ++l)
+        surface = vadd(surface, lighting(S, m, pat, node, l, over_point, eye_vector, normal_vector, L.shadowed[i * S.n_lights + l] != 0));
     V3 reflected = mk(0., 0., 0.), refracted = mk(0., 0., 0.);
     unsigned flags = L.flags[i];
-    int c0 = L.child_refl[i], c1 = L.child_refr[i];
+    const int c0 = L.child_refl[i], c1 = L.child_refr[i];
     if (has_next && c0 >= 0) {
-        reflected = vmul(mk(N.cr[c0], N.cg[c0], N.cb[c0]), L.k_refl[i]);
+        reflected = vmul(mk(N.cr[c0], N.cg[c0], N.cb[c0]), reflective);
         flags |= N.flags[c0];
     }
     if (has_next && c1 >= 0) {
-        refracted = vmul(mk(N.cr[c1], N.cg[c1], N.cb[c1]), L.k_transp[i]);
+        refracted = vmul(mk(N.cr[c1], N.cg[c1], N.cb[c1]), transparency);
         flags |= N.flags[c1];
     }
     V3 out;
-    if (L.mode[i]) {
-        double reflectance = L.k_schlick[i];
+    if (reflective > 0. && transparency > 0.) {  // src/world.rs:71-75
+        const double reflectance = walked ? schlick(eye_vector, normal_vector, n1, n2) : 0.;  // see needs_walk
         out = vadd(vadd(surface, vmul(reflected, reflectance)), vmul(refracted, (1. - reflectance)));
     } else {
         out = vadd(vadd(surface, reflected), refracted);
