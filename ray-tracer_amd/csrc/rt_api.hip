@@ -755,6 +755,27 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     // by the n1/n2 walk, which leaves n1 = n2 = 0 and makes schlick 0/0 = NaN — and NaN * BLACK is NaN, not BLACK
     for (int n = 0; n < d.n_nodes; ++n)
         if (d.node_kind[n] != RT_GROUP && d.node_kind[n] != RT_CSG && d.node_eq_class[n] < 0) s->ds.walk_at_zero = 1;
+    {   // WalkSink's shortcut (rt_kernels.hip.h) needs every mesh triangle to be equal to no other node of the scene: its
+        // equality class (>= 0) is carried by that node alone, or it is not even equal to itself (-1)
+        std::map<int32_t, int> uses;
+        for (int n = 0; n < d.n_nodes; ++n)
+            if (d.node_kind[n] <= RT_SMOOTH_TRIANGLE && d.node_eq_class[n] >= 0) uses[d.node_eq_class[n]]++;
+        bool unique = true;
+        for (const MeshTri& t : prog.mesh_tris) {
+            const int32_t c = d.node_eq_class[t.node];
+            if (c >= 0 && uses[c] != 1) unique = false;
+        }
+        for (int32_t m = 0; unique && size_t(m) < prog.mesh_dups.size();) {  // [count, node...] lists of repeated triangles
+            const int32_t cnt = prog.mesh_dups[size_t(m)];
+            for (int32_t j = 1; j <= cnt; ++j) {
+                const int32_t c = d.node_eq_class[prog.mesh_dups[size_t(m + j)]];
+                if (c >= 0 && uses[c] != 1) unique = false;
+            }
+            m += cnt + 1;
+        }
+        const char* e = std::getenv("RT_AMD_PASSIVE_TRIS");  // 0: never (A/B tests of the shortcut)
+        s->ds.passive_mesh_tris = unique && !(e && e[0] == '0') ? 1 : 0;
+    }
     if (std::getenv("RT_AMD_VERBOSE"))
         std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items, %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
                      d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),

@@ -75,7 +75,8 @@ struct DScene {
     int32_t n_lds;                    // BVH nodes [0, n_lds) are staged in LDS by the traversal kernels
     int32_t walk_at_zero;             // 1: some refractive index is not finite-positive, or some leaf is not equal to
                                       //    itself (F14): the n1/n2 walk cannot be skipped at remaining == 0 (needs_walk)
-    int32_t _pad;
+    int32_t passive_mesh_tris;        // 1: every triangle of a mesh BVH is equal (Shape::eq) to no other node: WalkSink may drop
+                                      //    all but the last of them below the hit (rt_kernels.hip.h)
     int32_t* spill;                   // [BVH_STACK - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
     long long spill_lanes;
 };

@@ -107,8 +107,11 @@ struct ClosestSink {
         flags = 0;
         stop_below = -INFINITY;
     }
+    static constexpr bool FAR_FIRST = false;
     __device__ __forceinline__ bool done() const { return best_t < stop_below; }
     __device__ __forceinline__ double lo() const { return NEED_FIRST ? -INFINITY : 0.; }
+    __device__ __forceinline__ double lo_mesh() const { return lo(); }
+    __device__ __forceinline__ void emit_mesh(double t, int key, double u, double v, int uv) { emit(t, key, u, v, uv); }
     __device__ __forceinline__ double hi() const { return best_t; }
     __device__ __forceinline__ void emit(double t, int key, double u, double v, int uv) {
         if (t != t) flags |= RT_FLAG_NAN_T;
@@ -123,7 +126,10 @@ struct ClosestSink {
 
 // Everything with t <= limit or near_eq(t, limit), kept as an unsorted bounded list (sorted by the caller).
 struct ListSink {
+    static constexpr bool FAR_FIRST = false;
     __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ double lo_mesh() const { return lo(); }
+    __device__ __forceinline__ void emit_mesh(double tt, int k, double u, double v, int uv) { emit(tt, k, u, v, uv); }
     double* t;    // [LIST_CAP], private
     int* key;
     int n;        // true count (may exceed cap)
@@ -136,6 +142,53 @@ struct ListSink {
         if (tt != tt) flags |= RT_FLAG_NAN_T;
         if (tt <= limit || fabs(tt - limit) < EPS) {
             if (n < cap) { t[n] = tt; key[n] = k; } else flags |= RT_FLAG_LIST_OVERFLOW;
+            ++n;
+        }
+    }
+};
+
+// The list of the n1/n2 walk (container_walk): ListSink, except that the triangles of a mesh BVH are "passive" when the
+// scene allows it (DScene::passive_mesh_tris: every mesh triangle is equal to no other shape of the scene).  A passive
+// entry is never the hit (any triangle but the hit node), so in the reference's loop (src/intersection.rs:54-80) it is
+// pushed onto `containers`, never found there, never removed: all it can do is BE containers.last() — or make the
+// vector non-empty — when an entry of the hit object within EPSILON of the hit's t is processed.  Those entries all
+// have t > hit_t - EPSILON, so of the passive entries with t <= hit_t - 2 EPSILON only the LAST one in list order (the
+// maximum (t, key)) can ever be observed; it is kept, the others are dropped, and passive entries inside the window
+// above that are all kept.  The walk's result is unchanged and the mesh traversal turns from an enumeration of the whole
+// line into a pruned search (boxes that end below the best entry so far are skipped, far children first).
+struct WalkSink {
+    static constexpr bool FAR_FIRST = true;
+    __device__ __forceinline__ bool done() const { return false; }
+    double* t;    // [LIST_CAP], private
+    int* key;
+    int n;        // true count (may exceed cap)
+    int cap;
+    double limit;
+    unsigned flags;
+    double below_t;   // the passive entry kept from below the window
+    int below_key;
+    int hit_node;
+    bool passive;
+    __device__ __forceinline__ double lo() const { return -INFINITY; }
+    __device__ __forceinline__ double lo_mesh() const { return passive ? below_t : -INFINITY; }
+    __device__ __forceinline__ double hi() const { return limit + 2. * EPS; }
+    __device__ __forceinline__ void emit(double tt, int k, double, double, int) {
+        if (tt != tt) flags |= RT_FLAG_NAN_T;
+        if (tt <= limit || fabs(tt - limit) < EPS) {
+            if (n < cap) { t[n] = tt; key[n] = k; } else flags |= RT_FLAG_LIST_OVERFLOW;
+            ++n;
+        }
+    }
+    __device__ __forceinline__ void emit_mesh(double tt, int k, double u, double v, int uv) {
+        if (passive && (k >> 2) != hit_node && tt <= limit - 2. * EPS) {
+            if (tt > below_t || (tt == below_t && k > below_key)) { below_t = tt; below_key = k; }
+            return;
+        }
+        emit(tt, k, u, v, uv);
+    }
+    __device__ __forceinline__ void finish() {  // the kept entry joins the list (its place comes from the sort)
+        if (below_key >= 0) {
+            if (n < cap) { t[n] = below_t; key[n] = below_key; } else flags |= RT_FLAG_LIST_OVERFLOW;
             ++n;
         }
     }
@@ -500,7 +553,7 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             }
             bump<COUNT>(w.bvh_nodes);
             bump<COUNT>(w.box, 4);
-            const double tlo = full_line ? -INFINITY : sink.lo();
+            const double tlo = full_line ? -INFINITY : sink.lo_mesh();
             const double thi = sink.hi();
             float tn[4];
             if (rf.ok) {
@@ -523,7 +576,12 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                     if (!hit) ch[c] = INT32_MIN;
                 }
             }
-            // nearest first (order only matters for how soon the closest-hit bound tightens)
+            // nearest first (order only matters for how soon the closest-hit bound tightens); a search for the LAST entry
+            // below a bound (WalkSink) wants the far children first
+            if (Sink::FAR_FIRST) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tn[c] = ch[c] != INT32_MIN ? -tn[c] : INFINITY;
+            }
             cswap(tn[0], ch[0], tn[1], ch[1]);
             cswap(tn[2], ch[2], tn[3], ch[3]);
             cswap(tn[0], ch[0], tn[2], ch[2]);
@@ -624,6 +682,10 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         } else {
             sink.emit(t, key, u, v, uv);
         }
+    };
+    auto out_mesh = [&](double t, int key, double u, double v, int uv) {  // from a mesh BVH leaf
+        if (HAS_CSG && cs->depth > 0) out(t, key, u, v, uv);
+        else sink.emit_mesh(t, key, u, v, uv);
     };
     const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
     const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
@@ -737,9 +799,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
             const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
             double tnear;
             bump<COUNT>(w.box);
-            if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo(), sink.hi(), tnear))
+            if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo_mesh(), sink.hi(), tnear))
             {
-                bvh_traverse<COUNT>(S, M, it.a, o, d, inv, sink, full_line, w, out);
+                bvh_traverse<COUNT>(S, M, it.a, o, d, inv, sink, full_line, w, out_mesh);
             }
             continue;
         }
@@ -1153,9 +1215,11 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
                                                double& n1_out, double& n2_out, unsigned& flags, bool alive) {
     double lt[LIST_CAP];
     int lk[LIST_CAP];
-    ListSink sink;
+    WalkSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
+    sink.below_t = -INFINITY; sink.below_key = -1; sink.hit_node = hit_node; sink.passive = S.passive_mesh_tris != 0;
     traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
+    sink.finish();
     flags |= sink.flags;
     const int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
     const int hit_cls = alive ? S.node_eq_class[hit_node] : -1;

@@ -494,6 +494,49 @@ def test_world_space_cull_ranges_change_nothing(monkeypatch):
     assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
 
 
+def _glass_mesh_world(instanced):
+    """Transparent things in front of, behind and inside triangle meshes: the n1/n2 walk's lists hold many mesh
+    triangles.  `instanced`: the same parsed mesh under two groups (its triangles then share equality classes, and the
+    walk must keep every one of them)."""
+    w = World()
+    w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+    w.objects.append(Shape.plane().set_transform(translate(0., -0.4, 0.)).set_material(Material(reflective=0.2, pattern=Pattern.checkered(rt.WHITE, rt.BLACK))))
+    teapot, _ = rt.obj_to_group(scenes.read_asset("teapot.obj"))
+    teapot.set_transform(scale(0.45, 0.45, 0.45)).set_material(
+        Material(color=(0.9, 0.95, 1.), diffuse=0.2, reflective=0.3, transparency=0.8, refractive_index=1.33))
+    w.objects.append(teapot)
+    if instanced:
+        g2 = Shape.group().set_transform(translate(2.5, 0., 1.))
+        g2.add_child(teapot.clone())
+        w.objects.append(g2)
+    for k, (x, z) in enumerate(((-2.2, -1.), (0.3, -2.6), (2.4, -1.5))):
+        w.objects.append(Shape.glass_sphere().set_transform(translate(x, 0.6, z) * scale(0.9, 0.9, 0.9)).set_material(
+            Material(color=(1., 1., 1.), diffuse=0.1, reflective=0.6, transparency=0.9, refractive_index=1.5 + 0.2 * k)))
+    cam = Camera(64, 36, PI / 3)
+    cam.transform = view_transform((0.5, 2.4, -7.5), (0.2, 0.8, 0.), (0., 1., 0.))
+    return w, cam
+
+
+def test_passive_mesh_triangles_in_the_n1_n2_walk_change_nothing(monkeypatch):
+    """WalkSink (rt_kernels.hip.h) keeps only the last mesh triangle below the hit: pure acceleration.  Glass teapot
+    among glass spheres against the oracle, and bit-identical with the shortcut turned off; an instanced mesh (equal
+    triangles in two places) must turn it off by itself and still match."""
+    for instanced in (False, True):
+        w, cam = _glass_mesh_world(instanced)
+        g, o = assert_image_parity(w, cam)
+        assert g.stats.rays_container > 300 and g.stats.rays_refract > 300
+        monkeypatch.setenv("RT_AMD_PASSIVE_TRIS", "0")
+        w0, cam0 = _glass_mesh_world(instanced)
+        plain = cam0.render(w0)
+        monkeypatch.delenv("RT_AMD_PASSIVE_TRIS")
+        assert np.array_equal(plain.rgb, g.rgb, equal_nan=True) and np.array_equal(plain.flags, g.flags)
+        assert plain.stats.total_rays == g.stats.total_rays and plain.stats.rays_container == g.stats.rays_container
+        ro, rd = _random_rays(300, 13 + instanced, center=(0.3, 0.8, -0.5), radius=6.)
+        g_rgb, g_id, g_fl = w.color_at_batch(ro, rd, 5)
+        o_rgb, o_id, o_fl = ob.color_at_batch(w, ro, rd, 5)
+        assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+
+
 def test_gpu_built_bvh_changes_nothing(monkeypatch):
     """RT_AMD_DEVICE_BVH=1: meshes of 1024+ triangles take their tree topology from the GPU (Morton sort + binary radix
     tree, csrc/rt_lbvh.hip).  A BVH only decides which triangles get tested: renders are bit-identical to those with the
