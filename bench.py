@@ -180,6 +180,21 @@ def main():
     elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # ---- SURVEY 8(d)'s literal metric, reported next to `value`: rt_render = the same frame with HOST output buffers
+    # (one 49.8 MB D2H copy of the f64 frame at 1080p included).  Never `value`: that is the HBM-resident rate.
+    host_ms = None
+    if world == 1:
+        host_rgb = np.zeros((args.height, args.width, 3))
+        for _ in range(2):
+            rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), host_rgb.ctypes.data_as(rt.c_dp), None, None, None)
+        n_host = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            rc = rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), host_rgb.ctypes.data_as(rt.c_dp), None, None, None)
+            if rc < 0:
+                raise RuntimeError(rt.last_error())
+        host_ms = (time.perf_counter() - t0) / n_host * 1e3
+
     # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
     st = rt.Stats()
     step(st)
@@ -234,6 +249,12 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
                     "peak_measured": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured": round(achieved / FP64_VALU_MEASURED_TFLOPS, 5),
                     "launches_per_frame": n_launch, "avg_launch_ms": round(ms[dom] / n_launch, 5),
+                    "source": "HIP events on the launch stream around every launch of %d rt_stats frames; those frames run "
+                              "the same launch schedule as the timed frames (plain enqueue where the timed frames replay "
+                              "it as one HIP graph), no host wait between launches" % n_ev,
+                    "flops_source": "work counters of one instrumented frame (want_counters=1) x SURVEY 8(d) constants",
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; "
+                                      "not collected in this run)",
                     "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
@@ -279,6 +300,12 @@ def main():
                           "parallelism": "tile-shard x%d, RCCL gather" % world if world > 1 else "single GPU"},
                "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
                                   "total": total_rays, "shaded_nodes": rays[4]},
+               "value_is": "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), scene resident before the "
+                           "timed region",
+               "rt_render_host": None if host_ms is None else {
+                   "ms_per_frame": round(host_ms, 4), "Mrays_s": round(total_rays / (host_ms * 1e-3) / 1e6, 3),
+                   "what": "rt_render: the same frame into a HOST f64 buffer, D2H copy of %.1f MB included (SURVEY 8(d)'s "
+                           "wording of the metric; PCIe-inclusive, so never `value`)" % (args.height * args.width * 24 / 1e6)},
                "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
                "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

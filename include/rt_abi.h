@@ -218,21 +218,23 @@ typedef struct rt_stats {
     int64_t shaded_nodes;   /* nodes of the recursion tree that hit something                         */
     int32_t levels;         /* recursion levels that held at least one ray                            */
     int32_t _pad;
-    /* device time per kernel class, ms, measured with HIP events on the launch stream */
+    /* device time per kernel class, ms, measured with HIP events on the launch stream around every launch of the SAME
+     * schedule the untimed calls run (no host wait between launches; the events are read after the frame) */
     double ms_total;
     double ms_raygen;
-    double ms_trace;   /* closest-hit traversal launches  */
-    double ms_shadow;  /* shadow traversal launches       */
-    double ms_collect; /* container-list launches         */
-    double ms_shade;   /* k_prepare + k_finish            */
-    double ms_resolve; /* bottom-up colour resolve        */
-    int32_t n_trace_launches;
-    int32_t n_shadow_launches;
+    double ms_trace;   /* k_trace launches: closest hits of level d + the shadow rays of level d-1, one launch per level,
+                          plus one for the shadow rays of the last level                                                */
+    double ms_shadow;  /* always 0: the shadow rays have no launch of their own (kept for ABI stability)                */
+    double ms_collect; /* k_walk launches: the n1/n2 container walks                                                    */
+    double ms_shade;   /* k_queue + k_spawn (queue compaction, reflection / refraction ray spawn)                       */
+    double ms_resolve; /* k_shade: lighting + schlick + bottom-up blend                                                 */
+    int32_t n_trace_launches;  /* k_trace launches                                                                      */
+    int32_t n_shadow_launches; /* k_walk launches                                                                       */
     /* algorithmic work counted by the instrumented kernels (want_counters = 1), per kernel class; the
      * RT_WORK_* indices name the rows, SURVEY.md section 8(d) constants turn them into flops / bytes */
-    int64_t work_trace[RT_WORK_COUNT];     /* closest-hit launches (k_trace)      */
-    int64_t work_shadow[RT_WORK_COUNT];    /* shadow launches (k_shadow)          */
-    int64_t work_container[RT_WORK_COUNT]; /* container-list launches (k_container) */
+    int64_t work_trace[RT_WORK_COUNT];     /* closest-hit part of k_trace         */
+    int64_t work_shadow[RT_WORK_COUNT];    /* shadow-ray part of k_trace          */
+    int64_t work_container[RT_WORK_COUNT]; /* k_walk                              */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* opaque: device-resident tables + acceleration structure + queues */
@@ -284,6 +286,28 @@ int32_t rt_scene_meshes_built_on_gpu(const rt_scene* scene);
  * rt_render_shard. */
 int rt_render_frame(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_frame,
                     int32_t* d_hit_id_frame, uint8_t* d_flags_frame, rt_stats* stats_out);
+
+/* ---- one process, several GPUs of one node (no counterpart in the reference, which is
+ * single-threaded CPU code: this is the n_gpus of the Camera::render_gpu(world, depth, n_gpus) a host binds) ----
+ *
+ * rt_scene_create_multi: like rt_scene_create on each of n_gpus devices (`devices` [n_gpus], NULL = 0..n_gpus-1); the
+ * handle is that of the replica on devices[0] and owns the others: rt_scene_destroy frees everything, and every other
+ * entry point (rt_render, rt_color_at, ...) works on it as on a single-GPU scene of devices[0].
+ * rt_render_multi: Camera::render (src/camera.rs:62-74) with the (hsize-1)x(vsize-1) pixel domain cut into 8x8 tiles
+ * dealt round-robin to the devices (pixels are independent, src/camera.rs:65-71; a pixel's value does not depend on
+ * the partition), one host thread per device, the shards gathered to devices[0] with ONE ncclGather per array (RCCL
+ * over xGMI, loaded on first use; hipMemcpyPeerAsync when RCCL cannot be used — rt_scene_gather_kind tells which) and
+ * scattered into the row-major frame there.  Outputs are HOST buffers as in rt_render, all nullable except that one of
+ * rgb_out / quantised_out must be given: quantised_out [vsize*hsize*3] receives scale_color (src/canvas.rs:86-98) of
+ * the frame, computed on each device before the gather (an 8x smaller gather and D2H copy than the f64 frame).
+ * stats_per_gpu: NULL or [n_gpus].  opts->rank / n_ranks / stream are ignored. */
+int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, rt_scene** out);
+int rt_render_multi(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
+                    int32_t* hit_id_out, uint8_t* flags_out, uint8_t* quantised_out, rt_stats* stats_per_gpu);
+/* Replicas of the scene (1 for rt_scene_create), and how rt_render_multi gathers: 0 nothing to gather (one GPU),
+ * 1 ncclGather (RCCL), 2 hipMemcpyPeerAsync. */
+int32_t rt_scene_gpu_count(const rt_scene* scene);
+int32_t rt_scene_gather_kind(const rt_scene* scene);
 
 /* Scatter gathered shards (concatenated in rank order, DEVICE memory, on `scene`'s device) into a full
  * row-major frame, zero elsewhere.  d_rgb_frame [vsize*hsize*3] device.  d_hit_id_* nullable. */

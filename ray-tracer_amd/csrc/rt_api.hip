@@ -2,6 +2,7 @@
 //
 // The product path is HIP only.  There is no CPU implementation behind these entry points: without a gfx950
 // device every call that would compute fails with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -10,9 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.h"
@@ -79,6 +84,7 @@ struct GrowBuf {
     size_t bytes = 0;
 };
 
+struct MultiState;
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -106,6 +112,7 @@ struct rt_scene {
     size_t trav_lds_bytes = 0;
     int n_cus = 1;
     std::map<const void*, int> trav_grid;  // kernel -> workgroups that are resident at once on the whole device
+    struct MultiState* multi = nullptr;    // rt_scene_create_multi: replicas on other devices, worker threads, RCCL
 };
 
 namespace {
@@ -635,7 +642,142 @@ bool check_scene(rt_scene* s) {
     return true;
 }
 
+
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+// One process, one host thread per device: the scene is replicated, the image is cut into 8x8
+// tiles dealt round-robin to the devices, every device renders its shard into its own HBM, and ONE gather brings the
+// (equally sized, padded) shard buffers to device 0 over xGMI — ncclGather of RCCL, nothing is reduced — where
+// k_assemble scatters them into the row-major frame.  RCCL is loaded with dlopen the first time a multi-GPU scene is
+// created (a single-GPU host never loads it, and a process that already holds a copy — PyTorch bundles one — shares
+// it); when it cannot be used (not loadable, or the device list names one device twice, which the tests on a one-GPU
+// box do) the gather falls back to hipMemcpyPeerAsync, one copy per peer on the peer's stream.
+struct RcclApi {
+    typedef int (*comm_init_all_t)(void**, int, const int*);
+    typedef int (*comm_destroy_t)(void*);
+    typedef int (*group_t)();
+    typedef int (*gather_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_t)(int);
+    void* lib = nullptr;
+    comm_init_all_t comm_init_all = nullptr;
+    comm_destroy_t comm_destroy = nullptr;
+    group_t group_start = nullptr, group_end = nullptr;
+    gather_t gather = nullptr;
+    errstr_t errstr = nullptr;
+    std::string why;  // why it is not usable
+    bool ok() const { return lib != nullptr; }
+};
+constexpr int NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_FLOAT64 = 8;  // ncclDataType_t, rccl.h:459-467
+
+static RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)  // a copy the process already holds (PyTorch's bundled one has no soname)
+            if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) { a.why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?"); return a; }
+        a.comm_init_all = reinterpret_cast<RcclApi::comm_init_all_t>(dlsym(a.lib, "ncclCommInitAll"));
+        a.comm_destroy = reinterpret_cast<RcclApi::comm_destroy_t>(dlsym(a.lib, "ncclCommDestroy"));
+        a.group_start = reinterpret_cast<RcclApi::group_t>(dlsym(a.lib, "ncclGroupStart"));
+        a.group_end = reinterpret_cast<RcclApi::group_t>(dlsym(a.lib, "ncclGroupEnd"));
+        a.gather = reinterpret_cast<RcclApi::gather_t>(dlsym(a.lib, "ncclGather"));
+        a.errstr = reinterpret_cast<RcclApi::errstr_t>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.comm_init_all || !a.comm_destroy || !a.group_start || !a.group_end || !a.gather || !a.errstr) {
+            a.why = "librccl lacks ncclCommInitAll / ncclGather / ...";
+            a.lib = nullptr;
+        }
+        return a;
+    }();
+    return api;
+}
+
+// A host thread bound to one replica: runs one job at a time, the caller waits for it.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = RT_OK;
+    std::string err;
+    Worker() {
+        th = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            while (true) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                has_job = false;
+                std::function<int()> f = std::move(job);
+                lk.unlock();
+                rt_set_error("%s", "");
+                const int r = f();
+                const std::string e = rt_last_error();
+                lk.lock();
+                rc = r;
+                err = e;
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void start(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return done; });
+        return rc;
+    }
+    ~Worker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
+struct MultiState {
+    std::vector<rt_scene*> replicas;  // [0] is the scene that owns this state; the others are whole scenes of their own
+    std::vector<int> devices;
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<void*> comms;         // ncclComm_t per replica when the gather is RCCL's
+    std::vector<hipEvent_t> sent;     // peer-copy gather: replica r's copy has been enqueued
+    std::vector<GrowBuf> shard_q;     // per replica: quantised shard (u8 gather)
+    GrowBuf g_rgb, g_q, g_id, g_flags, frame_q;  // on the root: gathered shards, u8 frame
+    int gather_kind = 0;              // 0: one device, nothing to gather; 1: ncclGather; 2: hipMemcpyPeerAsync
+    std::string gather_note;
+};
+
+// Runs f(r) on every replica's worker thread (device r current) and waits for all; first error wins.
+template <class F>
+int on_all_replicas(MultiState* ms, F f) {
+    const size_t n = ms->replicas.size();
+    for (size_t r = 0; r < n; ++r)
+        ms->workers[r]->start([ms, r, f]() -> int {
+            hipError_t e = hipSetDevice(ms->devices[r]);
+            if (e != hipSuccess) { rt_set_error("hipSetDevice(%d): %s", ms->devices[r], hipGetErrorString(e)); return RT_ERR_HIP; }
+            return f(int(r));
+        });
+    int rc = RT_OK;
+    for (size_t r = 0; r < n; ++r) {
+        const int rr = ms->workers[r]->wait();
+        if (rr != RT_OK && rc == RT_OK) {
+            rc = rr;
+            rt_set_error("device %d (replica %zu): %s", ms->devices[r], r, ms->workers[r]->err.c_str());
+        }
+    }
+    return rc;
+}
+
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -802,6 +944,23 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
+    if (MultiState* ms = s->multi) {  // the owner of a multi-GPU scene takes its replicas with it
+        s->multi = nullptr;
+        ms->workers.clear();  // joins the threads
+        if (ms->gather_kind == 1)
+            for (void* c : ms->comms)
+                if (c) (void)rccl_api().comm_destroy(c);
+        for (size_t r = 0; r < ms->replicas.size(); ++r) {
+            (void)hipSetDevice(ms->devices[r]);
+            if (r < ms->sent.size() && ms->sent[r]) (void)hipEventDestroy(ms->sent[r]);
+            if (r < ms->shard_q.size() && ms->shard_q[r].p) (void)hipFree(ms->shard_q[r].p);
+            if (r > 0) rt_scene_destroy(ms->replicas[r]);
+        }
+        (void)hipSetDevice(s->device);
+        for (GrowBuf* b : {&ms->g_rgb, &ms->g_q, &ms->g_id, &ms->g_flags, &ms->frame_q})
+            if (b->p) (void)hipFree(b->p);
+        delete ms;
+    }
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : s->allocs) (void)hipFree(p);
@@ -922,6 +1081,185 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->frame_id.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->frame_flags.p, npx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, rt_scene** out) {
+    if (!desc || !out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (n_gpus < 1 || n_gpus > 64) { rt_set_error("n_gpus must be 1..64 (got %d)", n_gpus); return RT_ERR_BAD_ARG; }
+    const int ndev = rt_device_count();
+    if (ndev <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
+    std::unique_ptr<MultiState> ms(new MultiState());
+    bool distinct = true;
+    for (int r = 0; r < n_gpus; ++r) {
+        const int dev = devices ? devices[r] : r;
+        if (dev < 0 || dev >= ndev) { rt_set_error("device %d out of range (have %d)", dev, ndev); return RT_ERR_NO_DEVICE; }
+        for (int q : ms->devices) distinct = distinct && q != dev;
+        ms->devices.push_back(dev);
+    }
+    ms->replicas.assign(size_t(n_gpus), nullptr);
+    ms->sent.assign(size_t(n_gpus), nullptr);
+    ms->shard_q.resize(size_t(n_gpus));
+    for (int r = 0; r < n_gpus; ++r) ms->workers.emplace_back(new Worker());
+    // every device compiles and uploads its own copy of the tables, in parallel (scene tables are small next to HBM:
+    // the teapot is ~1.3 MB, a 1 M-triangle grid ~0.3 GB)
+    MultiState* m = ms.get();
+    int rc = on_all_replicas(m, [m, desc](int r) -> int {
+        int rc2 = rt_scene_create(desc, m->devices[size_t(r)], &m->replicas[size_t(r)]);
+        if (rc2 != RT_OK) return rc2;
+        HIP_TRY(hipEventCreateWithFlags(&m->sent[size_t(r)], hipEventDisableTiming));
+        return RT_OK;
+    });
+    if (rc != RT_OK) {
+        const std::string keep = rt_last_error();
+        m->workers.clear();
+        for (int r = 0; r < n_gpus; ++r) {
+            (void)hipSetDevice(m->devices[size_t(r)]);
+            if (m->sent[size_t(r)]) (void)hipEventDestroy(m->sent[size_t(r)]);
+            if (m->replicas[size_t(r)]) rt_scene_destroy(m->replicas[size_t(r)]);
+        }
+        rt_set_error("%s", keep.c_str());
+        return rc;
+    }
+    // ---- how the shards will travel
+    const char* want = std::getenv("RT_AMD_GATHER");  // "rccl": also for one device; "peer": never RCCL
+    const bool force_rccl = want && std::strcmp(want, "rccl") == 0, no_rccl = want && std::strcmp(want, "peer") == 0;
+    if (n_gpus > 1 || force_rccl) {
+        m->gather_kind = 2;
+        if (no_rccl) m->gather_note = "RT_AMD_GATHER=peer";
+        else if (!distinct) m->gather_note = "the device list names a device twice (RCCL wants one rank per GPU)";
+        else if (!rccl_api().ok()) m->gather_note = rccl_api().why;
+        else {
+            m->comms.assign(size_t(n_gpus), nullptr);
+            const int r2 = rccl_api().comm_init_all(m->comms.data(), n_gpus, m->devices.data());
+            if (r2 == 0) { m->gather_kind = 1; m->gather_note = "ncclGather (RCCL)"; }
+            else { m->gather_note = std::string("ncclCommInitAll failed: ") + rccl_api().errstr(r2); m->comms.clear(); (void)hipGetLastError(); }
+        }
+        if (m->gather_kind == 2) m->gather_note = "hipMemcpyPeerAsync: " + m->gather_note;
+    }
+    if (std::getenv("RT_AMD_VERBOSE")) std::fprintf(stderr, "rt_scene_create_multi: %d replicas, gather: %s\n", n_gpus, m->gather_kind ? m->gather_note.c_str() : "none");
+    (void)hipSetDevice(m->devices[0]);
+    rt_scene* root = m->replicas[0];
+    root->multi = ms.release();
+    *out = root;
+    return RT_OK;
+}
+
+int32_t rt_scene_gpu_count(const rt_scene* s) { return s ? (s->multi ? int32_t(s->multi->replicas.size()) : 1) : 0; }
+
+int32_t rt_scene_gather_kind(const rt_scene* s) { return s && s->multi ? s->multi->gather_kind : 0; }
+
+int rt_render_multi(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
+                    uint8_t* flags_out, uint8_t* quantised_out, rt_stats* stats_per_gpu) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !cam || (!rgb_out && !quantised_out)) { rt_set_error("null argument (one of rgb_out / quantised_out is required)"); return RT_ERR_BAD_ARG; }
+    MultiState* ms = s->multi;
+    if (!ms) { rt_set_error("rt_render_multi needs a scene from rt_scene_create_multi"); return RT_ERR_BAD_ARG; }
+    const int N = int(ms->replicas.size());
+    const long long n_max = rt_shard_pixel_count(cam, 0, N);  // shard 0 is never smaller than another
+    if (n_max < 0) { rt_set_error("bad camera size"); return RT_ERR_BAD_ARG; }
+    const bool want_rgb = rgb_out != nullptr, want_q = quantised_out != nullptr, want_id = hit_id_out != nullptr, want_fl = flags_out != nullptr;
+    const size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
+    // ---- every device: its shard into its own HBM (padded to n_max pixels so that one ncclGather moves them)
+    int rc = on_all_replicas(ms, [=](int r) -> int {
+        rt_scene* q = ms->replicas[size_t(r)];
+        int rc2;
+        if ((rc2 = grow(q->out_rgb, size_t(n_max) * 3 * sizeof(double))) != RT_OK) return rc2;
+        if (want_id && (rc2 = grow(q->out_id, size_t(n_max) * sizeof(int32_t))) != RT_OK) return rc2;
+        if (want_fl && (rc2 = grow(q->out_flags, size_t(n_max))) != RT_OK) return rc2;
+        if (want_q && (rc2 = grow(ms->shard_q[size_t(r)], size_t(n_max) * 3)) != RT_OK) return rc2;
+        rt_render_opts o = *opts;
+        o.rank = r;
+        o.n_ranks = N;
+        o.stream = nullptr;
+        CameraParams c;
+        long long n_slots = 0;
+        rc2 = render_shard_impl(q, cam, &o, q->stream, static_cast<double*>(q->out_rgb.p), want_id ? static_cast<int32_t*>(q->out_id.p) : nullptr,
+                                want_fl ? static_cast<uint8_t*>(q->out_flags.p) : nullptr, stats_per_gpu ? stats_per_gpu + r : nullptr, c, n_slots);
+        if (rc2 != RT_OK) return rc2;
+        if (want_q && n_slots > 0) {  // scale_color on the shard: the u8 shard is 8x smaller on the wire than the f64 one
+            hipLaunchKernelGGL(k_quantise, dim3(blocks_for(n_slots * 3)), dim3(BLOCK), 0, q->stream, static_cast<const double*>(q->out_rgb.p),
+                               n_slots * 3, static_cast<uint8_t*>(ms->shard_q[size_t(r)].p));
+            HIP_TRY(hipGetLastError());
+        }
+        return RT_OK;
+    });
+    if (rc != RT_OK) return rc;
+    // ---- gather to the root (device of replica 0), stream-ordered behind each replica's render
+    HIP_TRY(hipSetDevice(s->device));
+    const bool gathered = N > 1 || ms->gather_kind == 1;
+    if (gathered) {
+        if (want_rgb && (rc = grow(ms->g_rgb, size_t(N) * size_t(n_max) * 3 * sizeof(double))) != RT_OK) return rc;
+        if (want_q && (rc = grow(ms->g_q, size_t(N) * size_t(n_max) * 3)) != RT_OK) return rc;
+        if (want_id && (rc = grow(ms->g_id, size_t(N) * size_t(n_max) * sizeof(int32_t))) != RT_OK) return rc;
+        if (want_fl && (rc = grow(ms->g_flags, size_t(N) * size_t(n_max))) != RT_OK) return rc;
+    }
+    struct Part { bool on; GrowBuf* dst; size_t elem; int nccl_type; };
+    const Part parts[4] = {{want_rgb, &ms->g_rgb, 3 * sizeof(double), NCCL_FLOAT64}, {want_q, &ms->g_q, 3, NCCL_UINT8},
+                           {want_id, &ms->g_id, sizeof(int32_t), NCCL_INT32}, {want_fl, &ms->g_flags, 1, NCCL_UINT8}};
+    auto shard_ptr = [&](int r, int part) -> void* {
+        rt_scene* q = ms->replicas[size_t(r)];
+        return part == 0 ? q->out_rgb.p : part == 1 ? ms->shard_q[size_t(r)].p : part == 2 ? q->out_id.p : q->out_flags.p;
+    };
+    if (gathered && ms->gather_kind == 1) {
+        RcclApi& R = rccl_api();
+        for (int part = 0; part < 4; ++part) {
+            if (!parts[part].on) continue;
+            const size_t count = size_t(n_max) * (part == 0 ? 3 : part == 1 ? 3 : 1);  // elements of the part's datatype per rank
+            int e = R.group_start();
+            for (int r = 0; r < N && e == 0; ++r)
+                e = R.gather(shard_ptr(r, part), r == 0 ? parts[part].dst->p : nullptr, count, parts[part].nccl_type, 0, ms->comms[size_t(r)],
+                             ms->replicas[size_t(r)]->stream);
+            const int e2 = R.group_end();
+            if (e != 0 || e2 != 0) { rt_set_error("ncclGather failed: %s", R.errstr(e != 0 ? e : e2)); return RT_ERR_HIP; }
+        }
+    } else if (gathered) {
+        for (int r = 0; r < N; ++r) {
+            HIP_TRY(hipSetDevice(ms->devices[size_t(r)]));
+            hipStream_t sr = ms->replicas[size_t(r)]->stream;
+            for (int part = 0; part < 4; ++part) {
+                if (!parts[part].on) continue;
+                const size_t bytes = size_t(n_max) * parts[part].elem;
+                HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(parts[part].dst->p) + size_t(r) * bytes, s->device, shard_ptr(r, part),
+                                           ms->devices[size_t(r)], bytes, sr));
+            }
+            HIP_TRY(hipEventRecord(ms->sent[size_t(r)], sr));
+        }
+        HIP_TRY(hipSetDevice(s->device));
+        for (int r = 1; r < N; ++r) HIP_TRY(hipStreamWaitEvent(s->stream, ms->sent[size_t(r)], 0));
+    }
+    // ---- root: scatter the shards into the row-major frame(s), copy to the host
+    hipStream_t st = s->stream;
+    if (want_rgb) { if ((rc = grow(s->frame_rgb, npx * 3 * sizeof(double))) != RT_OK) return rc; HIP_TRY(hipMemsetAsync(s->frame_rgb.p, 0, npx * 3 * sizeof(double), st)); }
+    if (want_q) { if ((rc = grow(ms->frame_q, npx * 3)) != RT_OK) return rc; HIP_TRY(hipMemsetAsync(ms->frame_q.p, 0, npx * 3, st)); }
+    if (want_id) { if ((rc = grow(s->frame_id, npx * sizeof(int32_t))) != RT_OK) return rc; HIP_TRY(hipMemsetAsync(s->frame_id.p, 0, npx * sizeof(int32_t), st)); }
+    if (want_fl) { if ((rc = grow(s->frame_flags, npx)) != RT_OK) return rc; HIP_TRY(hipMemsetAsync(s->frame_flags.p, 0, npx, st)); }
+    for (int r = 0; r < N; ++r) {
+        CameraParams c;
+        long long n_slots = 0, n_valid = 0;
+        if ((rc = camera_params(cam, r, N, c, n_slots, n_valid)) != RT_OK) return rc;
+        if (n_slots == 0) continue;
+        const size_t off = gathered ? size_t(r) * size_t(n_max) : 0;
+        const double* rgb_in = want_rgb ? (gathered ? static_cast<const double*>(ms->g_rgb.p) : static_cast<const double*>(s->out_rgb.p)) + off * 3 : nullptr;
+        const uint8_t* q_in = want_q ? (gathered ? static_cast<const uint8_t*>(ms->g_q.p) : static_cast<const uint8_t*>(ms->shard_q[0].p)) + off * 3 : nullptr;
+        const int32_t* id_in = want_id ? (gathered ? static_cast<const int32_t*>(ms->g_id.p) : static_cast<const int32_t*>(s->out_id.p)) + off : nullptr;
+        const uint8_t* fl_in = want_fl ? (gathered ? static_cast<const uint8_t*>(ms->g_flags.p) : static_cast<const uint8_t*>(s->out_flags.p)) + off : nullptr;
+        hipLaunchKernelGGL(k_assemble_all, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, rgb_in, q_in, id_in, fl_in,
+                           want_rgb ? static_cast<double*>(s->frame_rgb.p) : nullptr, want_q ? static_cast<uint8_t*>(ms->frame_q.p) : nullptr,
+                           want_id ? static_cast<int32_t*>(s->frame_id.p) : nullptr, want_fl ? static_cast<uint8_t*>(s->frame_flags.p) : nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (want_rgb) HIP_TRY(hipMemcpyAsync(rgb_out, s->frame_rgb.p, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (want_q) HIP_TRY(hipMemcpyAsync(quantised_out, ms->frame_q.p, npx * 3, hipMemcpyDeviceToHost, st));
+    if (want_id) HIP_TRY(hipMemcpyAsync(hit_id_out, s->frame_id.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (want_fl) HIP_TRY(hipMemcpyAsync(flags_out, s->frame_flags.p, npx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (gathered && ms->gather_kind == 2)  // the peers' streams: their copies are done (the root waited on them); nothing pending
+        for (int r = 1; r < N; ++r) { HIP_TRY(hipSetDevice(ms->devices[size_t(r)])); HIP_TRY(hipStreamSynchronize(ms->replicas[size_t(r)]->stream)); }
+    if (gathered && ms->gather_kind == 1)  // RCCL's work on the peers' streams must be over before their buffers are rewritten
+        for (int r = 1; r < N; ++r) { HIP_TRY(hipSetDevice(ms->devices[size_t(r)])); HIP_TRY(hipStreamSynchronize(ms->replicas[size_t(r)]->stream)); }
+    HIP_TRY(hipSetDevice(s->device));
     return RT_OK;
 }
 

@@ -1743,6 +1743,23 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(CameraParams c, long long n_
     if (fl_out && fl_in) fl_out[p] = fl_in[slot];
 }
 
+// The same for every per-pixel array a multi-GPU gather brings to the root (rt_render_multi): f64 RGB, quantised u8 RGB,
+// hit ids, flags; null inputs are skipped.
+__global__ __launch_bounds__(BLOCK) void k_assemble_all(CameraParams c, long long n_slots, const double* __restrict__ rgb_in,
+                                                        const uint8_t* __restrict__ q_in, const int32_t* __restrict__ id_in,
+                                                        const uint8_t* __restrict__ fl_in, double* rgb_out, uint8_t* q_out, int32_t* id_out,
+                                                        uint8_t* fl_out) {
+    long long slot = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= n_slots) return;
+    int px, py;
+    if (!slot_to_pixel(c, slot, px, py)) return;
+    long long p = (long long)py * c.hsize + px;
+    if (rgb_in) { rgb_out[3 * p] = rgb_in[3 * slot]; rgb_out[3 * p + 1] = rgb_in[3 * slot + 1]; rgb_out[3 * p + 2] = rgb_in[3 * slot + 2]; }
+    if (q_in) { q_out[3 * p] = q_in[3 * slot]; q_out[3 * p + 1] = q_in[3 * slot + 1]; q_out[3 * p + 2] = q_in[3 * slot + 2]; }
+    if (id_in) id_out[p] = id_in[slot];
+    if (fl_in) fl_out[p] = fl_in[slot];
+}
+
 // Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
 template <int SC>
 __global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const double* __restrict__ origins,

@@ -131,7 +131,8 @@ class CMaterial(C.Structure):  # rth_material
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
                "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
-               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_last_error"]
+               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_render_multi",
+               "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
                 "rth_triangle_new", "rth_smooth_triangle_new", "rth_csg_new", "rth_hexagon", "rth_shape_clone",
@@ -169,6 +170,12 @@ lib.rt_canvas_to_ppm.restype = C.c_int64
 lib.rt_canvas_to_ppm_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]
 lib.rt_canvas_to_ppm_noalloc.restype = C.c_int64
+lib.rt_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.c_int32, c_ip, C.POINTER(C.c_void_p)]
+lib.rt_render_multi.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp, c_bp, C.POINTER(Stats)]
+lib.rt_scene_gpu_count.argtypes = [C.c_void_p]
+lib.rt_scene_gpu_count.restype = C.c_int32
+lib.rt_scene_gather_kind.argtypes = [C.c_void_p]
+lib.rt_scene_gather_kind.restype = C.c_int32
 
 for _n in ("rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform", "rth_matmul",
            "rth_material_default", "rth_shape_free", "rth_world_free"):
@@ -683,6 +690,46 @@ class Camera:
         _chk(lib.rt_render(world.scene(), C.byref(cd), C.byref(opts), _dp(rgb), ids.ctypes.data_as(c_ip),
                            flags.ctypes.data_as(c_bp), C.byref(st) if want_stats else None))
         return Image(rgb, ids, flags, st)
+
+
+class MultiScene:
+    """A scene replicated on several GPUs of one node (rt_scene_create_multi); render() is Camera::render with the image
+    tile-sharded over them and gathered to the first device (rt_render_multi)."""
+
+    def __init__(self, world, devices):
+        devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+        self.h = C.c_void_p()
+        self.n = len(devs)
+        _chk(lib.rt_scene_create_multi(world.flatten(), len(devs), devs.ctypes.data_as(c_ip), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib.rt_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def gather_kind(self):
+        return int(lib.rt_scene_gather_kind(self.h))
+
+    def render(self, camera, depth=DEFAULT_RECURSION, want_rgb=True, want_quantised=False):
+        cd = camera.desc()
+        opts = RenderOpts(max_depth=depth, rank=0, n_ranks=1, want_counters=0, stream=None)
+        rgb = np.zeros((camera.vsize, camera.hsize, 3)) if want_rgb else None
+        q = np.zeros((camera.vsize, camera.hsize, 3), dtype=np.uint8) if want_quantised else None
+        ids = np.zeros((camera.vsize, camera.hsize), dtype=np.int32)
+        flags = np.zeros((camera.vsize, camera.hsize), dtype=np.uint8)
+        stats = (Stats * self.n)()
+        _chk(lib.rt_render_multi(self.h, C.byref(cd), C.byref(opts), _dp(rgb) if want_rgb else None, ids.ctypes.data_as(c_ip),
+                                 flags.ctypes.data_as(c_bp), q.ctypes.data_as(c_bp) if want_quantised else None, stats))
+        img = Image(rgb, ids, flags, list(stats))
+        img.q = q
+        return img
 
 
 def canvas_to_ppm_device(scene, d_rgb_frame, hsize, vsize, d_quantised=None):

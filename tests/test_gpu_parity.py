@@ -719,3 +719,51 @@ def test_device_ppm_is_byte_identical_to_the_host_mirror():
     img = cam.render(world)
     text, _ = _device_ppm(world, img.rgb)
     assert text == img.to_ppm().encode()
+
+
+# ------------------------------------------------------------------ one process, several GPUs (rt_render_multi)
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_render_multi_equals_rt_render(devices):
+    """Scene replicated per device, 8x8 tiles round-robin, one host thread per replica, gather to the first device,
+    scatter into the frame: the same pixels as the single-GPU Camera::render, bit for bit, ids and flags included, and
+    the u8 frame equals scale_color of the f64 frame.  A one-GPU box can only name device 0 several times: replicas
+    then share the card and the gather takes the hipMemcpyPeerAsync path (RCCL wants one rank per GPU)."""
+    for builder, size, depth in ((scenes.mixed_scene, (333, 190), 5), (scenes.teapot_scene, (257, 131), 4)):
+        w, cam = builder(*size)
+        ref = cam.render(w, depth)
+        ms = rt.MultiScene(w, devices)
+        assert rt.lib.rt_scene_gpu_count(ms.h) == len(devices)
+        assert ms.gather_kind == (0 if len(devices) == 1 else 2)
+        for _ in range(2):   # twice: the second frame replays graphs on every replica
+            img = ms.render(cam, depth, want_quantised=True)
+            assert np.array_equal(img.rgb, ref.rgb, equal_nan=True)
+            assert np.array_equal(img.hit_id, ref.hit_id) and np.array_equal(img.flags, ref.flags)
+            assert np.array_equal(img.q, ref.quantised().astype(np.uint8))
+        assert sum(s.rays_primary for s in img.stats) == ref.stats.rays_primary
+        assert sum(s.rays_primary + s.rays_reflect + s.rays_refract + s.rays_shadow for s in img.stats) == ref.stats.total_rays
+        only_q = ms.render(cam, depth, want_rgb=False, want_quantised=True)
+        assert np.array_equal(only_q.q, img.q)
+        # the handle also serves the single-GPU entry points
+        cd = cam.desc()
+        opts = rt.RenderOpts(max_depth=depth, rank=0, n_ranks=1, want_counters=0, stream=None)
+        rgb = np.zeros_like(ref.rgb)
+        assert rt.lib.rt_render(ms.h, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), None, None, None) == 0
+        assert np.array_equal(rgb, ref.rgb, equal_nan=True)
+        ms.close()
+
+
+def test_render_multi_rccl_gather_on_one_device(monkeypatch):
+    """RT_AMD_GATHER=rccl makes even a one-device scene go through dlopen(librccl) + ncclCommInitAll + ncclGather (a
+    one-rank gather is a copy): the only RCCL path a one-GPU box can run.  Skipped when RCCL cannot initialise here."""
+    monkeypatch.setenv("RT_AMD_GATHER", "rccl")
+    w, cam = scenes.book_world(200, 100)
+    ref = cam.render(w)
+    ms = rt.MultiScene(w, [0])
+    monkeypatch.delenv("RT_AMD_GATHER")
+    if ms.gather_kind != 1:
+        ms.close()
+        pytest.skip("RCCL did not initialise on this box")
+    img = ms.render(cam, want_quantised=True)
+    assert np.array_equal(img.rgb, ref.rgb) and np.array_equal(img.hit_id, ref.hit_id)
+    assert np.array_equal(img.q, ref.quantised().astype(np.uint8))
+    ms.close()
