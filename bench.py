@@ -58,11 +58,11 @@ def work_bytes(w):
 
 def _cpu_band(job):
     """Worker of the all-cores CPU baseline: one row band of the strided sample, rendered by the C oracle."""
-    scene, width, height, depth, stride, y0, y1 = job
+    scene, width, height, depth, stride, y0, y1, grid = job
     import oracle_bridge as ob
     import scenes
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
-                "book": scenes.book_world, "grid": scenes.instanced_grid}
+                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=grid)}
     w, cam = builders[scene](width, height)
     t0 = time.perf_counter()
     img = ob.render(w, cam, depth, stride=stride, rows=(y0, y1))
@@ -78,7 +78,7 @@ def cpu_baseline_all_cores(args):
     rows = args.height - 1
     bands = cores * 4   # 4 bands per worker: glass / teapot rows cost far more than sky rows
     edges = [rows * b // bands for b in range(bands + 1)]
-    jobs = [(args.scene, args.width, args.height, args.depth, args.cpu_stride, edges[b], edges[b + 1]) for b in range(bands)]
+    jobs = [(args.scene, args.width, args.height, args.depth, args.cpu_stride, edges[b], edges[b + 1], args.grid) for b in range(bands)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_band, jobs, chunksize=1)
@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_low", "mixed", "book", "grid"])
+    ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=12)
     args = ap.parse_args()
@@ -128,19 +129,25 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
-                "book": scenes.book_world, "grid": scenes.instanced_grid}
+                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=args.grid)}
     w, cam = builders[args.scene](args.width, args.height)
     scene = w.scene(local_rank)          # flatten + upload + BVH build: outside the timed region
     cd = cam.desc()
     n_local = int(rt.lib.rt_shard_pixel_count(C.byref(cd), rank, world))
     counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, world)) for r in range(world)]
     n_max = max(counts)
-    shard = torch.zeros((n_max, 3), dtype=torch.float64, device=dev)
+    # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
+    # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
+    # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
+    shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 0)]
+    gather_done = [None, None]
     frame = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
     # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
     gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
     gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
     opts = rt.RenderOpts(max_depth=args.depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
+    torch_stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
+    state = {"k": 0}
 
     def step(stats=None):
         if world == 1:
@@ -150,16 +157,24 @@ def main():
             if rc < 0:
                 raise RuntimeError(rt.last_error())
             return
-        rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shard.data_ptr(), None, None,
+        b = state["k"] & 1
+        state["k"] += 1
+        if gather_done[b] is not None:
+            gather_done[b].synchronize()          # the gather that read this buffer two frames ago
+        # returns when the shard is complete in HBM (the library waits once per frame for its ray counters)
+        rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None,
                                     C.byref(stats) if stats is not None else None)
         if rc < 0:
             raise RuntimeError(rt.last_error())
-        dist.gather(shard, gathered, dst=0)              # RCCL gather over xGMI: no reduction, peers -> root
-        torch.cuda.synchronize()                         # every rank: the library's stream rewrites `shard` next frame
-        if rank == 0:
-            rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None, None)
+        dist.gather(shards[b], gathered, dst=0)   # RCCL gather over xGMI: no reduction, peers -> root; enqueued, not waited for
+        if rank == 0:                             # stream-ordered behind the gather on torch's stream
+            rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None,
+                                            C.c_void_p(torch_stream))
             if rc < 0:
                 raise RuntimeError(rt.last_error())
+        ev = torch.cuda.Event()
+        ev.record()
+        gather_done[b] = ev
 
     def barrier():
         if world > 1:
