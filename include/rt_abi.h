@@ -41,7 +41,8 @@ extern "C" {
 #define RT_ERR_UNSUPPORTED (-2)  /* non-affine transform, non-invertible camera, ...          */
 #define RT_ERR_HIP (-3)          /* a HIP runtime call failed (text has hipGetErrorString)    */
 #define RT_ERR_NO_DEVICE (-4)    /* no gfx950 device / device index out of range              */
-#define RT_ERR_OVERFLOW (-5)     /* a bounded per-ray scratch list overflowed (see flags too) */
+#define RT_ERR_OVERFLOW (-5)     /* rt_intersect_world / rt_is_shadowed: a ray needs more list entries than even the HBM
+                                    arena variants hold (32768; 8192 pending inside one CSG subtree)        */
 
 /* node kinds — enum Shape, src/shape.rs:25-37 (TestShape has no device counterpart) */
 #define RT_SPHERE 0          /* src/sphere.rs          */
@@ -89,9 +90,11 @@ extern "C" {
                                     u,v were used instead */
 #define RT_FLAG_NAN_T 2u         /* a NaN t reached a sort: reference panics in partial_cmp().unwrap()
                                     (src/world.rs:52, src/group.rs:59, src/csg.rs:71)                    */
-#define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list overflowed: more than 32 intersections pending inside one CSG
-                                  * subtree, or more than 256 at or before the hit in the n1/n2 container walk: the
-                                  * pixel's colour is then not guaranteed */
+#define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list overflowed even in the library's last resort: the kernels keep
+                                  * 32 pending intersections per CSG subtree (8 nested) and 256 list entries for the n1/n2
+                                  * walk in per-lane memory; a ray that needs more is traced again — automatically, inside
+                                  * the same call — by kernel variants whose lists live in an HBM arena (8192 / 64 nested /
+                                  * 32768).  Only beyond THOSE sizes is the flag ever seen (and the pixel not guaranteed). */
 
 /*
  * Flattened scene.  `nodes` is the intersection tree exactly as World::intersect_world walks it

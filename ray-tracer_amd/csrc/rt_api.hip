@@ -102,6 +102,16 @@ struct rt_scene {
     int counter_blocks = 0;
     GrowBuf out_rgb, out_id, out_flags, frame_rgb, frame_id, frame_flags, in_a, in_b, misc_a, misc_b, misc_c;
     std::vector<hipEvent_t> events;  // timing pool of the rt_stats path (events on the launch stream)
+    // Overflow fix-up (rays whose tree ran into a bounded per-lane list are traced again by the BIG kernel variants):
+    // the HBM arena those variants keep their lists in, the small grid they run with, and a second set of level queues
+    // and counters for the re-traced rays (parked here, swapped in by FixScope)
+    GrowBuf arena, ovf_index;
+    int arena_wgs = 0;
+    std::vector<LevelStore> fix_levels;
+    unsigned long long* fix_d_counters = nullptr;
+    unsigned long long* fix_h_counters = nullptr;
+    int fix_counter_blocks = 0;
+    bool big = false;  // the launches being enqueued are the BIG variants
     // The enqueue of a whole frame (~35 launches) is captured once into a HIP graph and replayed with one call while
     // everything it bakes in stays the same (camera, shard, depth, output pointers, queue blocks): `graph_key` is the
     // byte image of those.
@@ -277,6 +287,7 @@ int launch_trav(rt_scene* s, hipStream_t st, K kernel, long long n_chunks, A... 
         it = s->trav_grid.emplace(key, per_cu * s->n_cus).first;
     }
     long long grid = std::min<long long>(n_chunks, it->second);
+    if (s->big) grid = std::min<long long>(grid, s->arena_wgs);  // one arena slab per lane of this grid
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kernel, dim3(unsigned(grid)), dim3(TBLOCK), s->trav_lds_bytes, st, args...);
     return RT_OK;
@@ -298,6 +309,10 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const
                  unsigned long long* ctr, const Level& P, unsigned long long* prev, long long prev_upper) {
     const long long chunks = chunks_for(n) + (prev ? chunks_for(prev_upper * (s->n_lights > 0 ? s->n_lights : 1)) : 0);
     int rc = RT_OK;
+    if (s->big) {  // overflow fix-up: one variant serves every scene class (rt_kernels.hip.h: SC_BIG)
+        if (COUNT) { rt_set_error("internal: the BIG variants are not instrumented"); return RT_ERR_BAD_ARG; }
+        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev);
+    }
 #define RT_CALL(SC)                                                                                                            \
     rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)    \
                        : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)
@@ -308,6 +323,7 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const
 template <bool COUNT>
 int launch_walk(rt_scene* s, hipStream_t st, const Level& L, long long n_upper, unsigned long long* ctr) {
     int rc = RT_OK;
+    if (s->big) return launch_trav(s, st, k_walk<SC_CSG | SC_CULL | SC_BIG, false>, chunks_for(n_upper), s->ds, L, ctr);
 #define RT_CALL(SC) rc = launch_trav(s, st, k_walk<SC, COUNT>, chunks_for(n_upper), s->ds, L, ctr)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
@@ -418,7 +434,8 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         const Level& N = d < last ? s->levels[size_t(d) + 1].L : L;
         const bool exact = d == 0 || sync;
         const unsigned long long* n_dev = exact ? nullptr : counter_block(s, d - 1) + CNT_NEXT;
-        hipLaunchKernelGGL(k_shade, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev, d < last ? 1 : 0);
+        hipLaunchKernelGGL(k_shade, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev, d < last ? 1 : 0,
+                           d == 0 ? counter_block(s, 0) + CNT_OVERFLOW : (unsigned long long*)nullptr);
     }
     tm.end();
     HIP_TRY(hipGetLastError());
@@ -462,6 +479,93 @@ void fill_stats(rt_scene* s, int D, rt_stats* stats) {
     stats->levels = levels;
 }
 
+// ---- overflow fix-up ---------------------------------------------------------------------------------------------
+// Capacities of the BIG variants' lists by round (CSG pending intersections, n1/n2 / intersect_world list entries) and
+// the grid they run with; the arena is lanes x (csg * 28 + list * 16) bytes, about 1.5 GB in either round.
+struct ArenaRound { int csg_cap, list_cap, wgs; };
+constexpr ArenaRound ARENA_ROUNDS[] = {{1024, 4096, 16}, {8192, 32768, 2}};
+constexpr int N_ARENA_ROUNDS = int(sizeof ARENA_ROUNDS / sizeof ARENA_ROUNDS[0]);
+
+int ensure_arena(rt_scene* s, int round) {
+    const ArenaRound& a = ARENA_ROUNDS[round];
+    const long long lane_bytes = (long long)a.csg_cap * 28 + (long long)a.list_cap * 16;
+    int rc = grow(s->arena, size_t(lane_bytes) * size_t(a.wgs) * TBLOCK);
+    if (rc != RT_OK) return rc;
+    s->ds.arena = static_cast<char*>(s->arena.p);
+    s->ds.arena_lane_bytes = lane_bytes;
+    s->ds.arena_csg_cap = a.csg_cap;
+    s->ds.arena_list_cap = a.list_cap;
+    s->arena_wgs = a.wgs;
+    return RT_OK;
+}
+
+// While alive, the fix-up pass's own queues and counters sit in the scene's fields (and the frame's are parked).
+struct FixScope {
+    rt_scene* s;
+    explicit FixScope(rt_scene* scene) : s(scene) { swap(); }
+    ~FixScope() { swap(); }
+    void swap() {
+        std::swap(s->levels, s->fix_levels);
+        std::swap(s->d_counters, s->fix_d_counters);
+        std::swap(s->h_counters, s->fix_h_counters);
+        std::swap(s->counter_blocks, s->fix_counter_blocks);
+    }
+};
+
+int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats);
+
+// Level 0 (n0 rays, resolved, the stream waited for) holds `n_fix` rays flagged RT_FLAG_LIST_OVERFLOW: trace those
+// again with lists that are large enough and patch their colour, hit and flags back into level 0.  With `stats` the ray
+// accounting is corrected too: minus what the bounded pass counted for these rays (found by repeating it on them
+// alone), plus what the BIG pass counts.
+int fix_overflowed_rays(rt_scene* s, hipStream_t st, long long n0, long long n_fix, int D, rt_stats* stats) {
+    int rc = grow(s->ovf_index, size_t(n_fix) * sizeof(int32_t));
+    if (rc != RT_OK) return rc;
+    const Level main0 = s->levels[0].L;
+    unsigned long long* cursor = counter_block(s, 0) + CNT_OVERFLOW;  // reused as the append cursor
+    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), st));
+    long long still = n_fix;
+    {
+        FixScope scope(s);
+        if ((rc = ensure_level(s, 0, n_fix)) != RT_OK || (rc = ensure_counters(s, D + 2)) != RT_OK) return rc;
+        const Level fix0 = s->levels[0].L;
+        hipLaunchKernelGGL(k_collect_overflow, dim3(blocks_for(n0)), dim3(BLOCK), 0, st, main0, n0, cursor, static_cast<int32_t*>(s->ovf_index.p), fix0);
+        HIP_TRY(hipGetLastError());
+        Timer off{s, st, false};
+        rt_stats before, after;
+        std::memset(&before, 0, sizeof before);
+        if (stats) {  // what the bounded kernels did with these rays
+            rc = enqueue_levels_any(s, st, n_fix, D, true, false, off, nullptr);
+            if (rc != RT_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            fill_stats(s, D, &before);
+        }
+        for (int round = 0; round < N_ARENA_ROUNDS && still > 0; ++round) {
+            if ((rc = ensure_arena(s, round)) != RT_OK) return rc;
+            s->big = true;
+            rc = enqueue_levels_any(s, st, n_fix, D, true, false, off, nullptr);
+            s->big = false;
+            if (rc != RT_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            still = (long long)s->h_counters[CNT_OVERFLOW];
+        }
+        if (stats) {
+            std::memset(&after, 0, sizeof after);
+            fill_stats(s, D, &after);
+            stats->rays_reflect += after.rays_reflect - before.rays_reflect;
+            stats->rays_refract += after.rays_refract - before.rays_refract;
+            stats->shaded_nodes += after.shaded_nodes - before.shaded_nodes;
+            stats->rays_shadow += after.rays_shadow - before.rays_shadow;
+            stats->rays_container += after.rays_container - before.rays_container;
+            stats->levels = std::max(stats->levels, after.levels);
+        }
+        hipLaunchKernelGGL(k_patch_overflow, dim3(blocks_for(n_fix)), dim3(BLOCK), 0, st, main0, s->levels[0].L, n_fix, static_cast<const int32_t*>(s->ovf_index.p));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return RT_OK;
+}
+
 int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats) {
     return counters ? enqueue_levels<true>(s, st, n0, D, sync, tm, stats) : enqueue_levels<false>(s, st, n0, D, sync, tm, stats);
 }
@@ -480,7 +584,8 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, 
         if (!levels_overflowed(s, D)) {
             tm.collect();
             fill_stats(s, D, stats);
-            return RT_OK;
+            const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW];
+            return n_fix > 0 ? fix_overflowed_rays(s, st, n0, n_fix, D, stats) : RT_OK;
         }
         if (stats) {  // start the accounting over
             const int64_t primary = stats->rays_primary;
@@ -497,7 +602,8 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, 
     HIP_TRY(hipStreamSynchronize(st));
     tm.collect();
     fill_stats(s, D, stats);
-    return RT_OK;
+    const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW];
+    return n_fix > 0 ? fix_overflowed_rays(s, st, n0, n_fix, D, stats) : RT_OK;
 }
 
 int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams& c, long long& n_slots, long long& n_valid) {
@@ -593,13 +699,25 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         if (s->graph_exec) {
             HIP_TRY(hipGraphLaunch(s->graph_exec, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (!levels_overflowed(s, D)) return RT_OK;
+            if (!levels_overflowed(s, D)) {
+                const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW];
+                if (n_fix == 0) return RT_OK;
+                // rays that ran into a bounded list: traced again with the BIG variants, then the frame is written once more
+                if ((rc = fix_overflowed_rays(s, st, n_slots, n_fix, D, nullptr)) != RT_OK) return rc;
+                output();
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(st));
+                return RT_OK;
+            }
             // the view changed and a queue overflowed: the level-by-level walk below grows the queues (and the next
             // frame captures a new graph, its key holds the queue blocks)
             raygen();
             Timer off{s, st, false};
             rc = enqueue_levels<false>(s, st, n_slots, D, true, off, nullptr);
             if (rc != RT_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW])
+                if ((rc = fix_overflowed_rays(s, st, n_slots, n_fix, D, nullptr)) != RT_OK) return rc;
             output();
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));
@@ -968,6 +1086,12 @@ void rt_scene_destroy(rt_scene* s) {
         if (l.block) (void)hipFree(l.block);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    for (LevelStore& l : s->fix_levels)
+        if (l.block) (void)hipFree(l.block);
+    if (s->fix_d_counters) (void)hipFree(s->fix_d_counters);
+    if (s->fix_h_counters) (void)hipHostFree(s->fix_h_counters);
+    if (s->arena.p) (void)hipFree(s->arena.p);
+    if (s->ovf_index.p) (void)hipFree(s->ovf_index.p);
     for (GrowBuf* b : {&s->out_rgb, &s->out_id, &s->out_flags, &s->frame_rgb, &s->frame_id, &s->frame_flags, &s->in_a, &s->in_b,
                        &s->misc_a, &s->misc_b, &s->misc_c})
         if (b->p) (void)hipFree(b->p);
@@ -1365,6 +1489,41 @@ int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double
     return RT_OK;
 }
 
+// One pass of k_list over n rays given on the host; big: the variant whose lists live in the arena (ensure_arena first).
+static int list_pass(rt_scene* s, bool big, int64_t n, const double* origins, const double* directions, int32_t max_hits, int32_t* count_out,
+                     double* t_out, int32_t* object_id_out, uint8_t* flags_host) {
+    hipStream_t st = s->stream;
+    int rc;
+    const size_t rb = size_t(n) * 3 * sizeof(double), lb = size_t(n) * size_t(max_hits);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->misc_a, size_t(n) * sizeof(int32_t))) != RT_OK ||
+        (rc = grow(s->misc_b, lb * sizeof(double))) != RT_OK || (rc = grow(s->misc_c, lb * sizeof(int32_t))) != RT_OK ||
+        (rc = grow(s->out_flags, size_t(n))) != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->misc_b.p, 0, lb * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(s->misc_c.p, 0, lb * sizeof(int32_t), st));
+    const double* o = static_cast<const double*>(s->in_a.p);
+    const double* d = static_cast<const double*>(s->in_b.p);
+    int32_t* cnt = static_cast<int32_t*>(s->misc_a.p);
+    double* tt = static_cast<double*>(s->misc_b.p);
+    int32_t* ids = static_cast<int32_t*>(s->misc_c.p);
+    uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
+    s->big = big;
+    if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    else if (s->has_csg) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    else rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    s->big = false;
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(count_out, cnt, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t_out, tt, lb * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(object_id_out, ids, lb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags_host, fl, size_t(n), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
 int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t max_hits,
                        int32_t* count_out, double* t_out, int32_t* object_id_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
@@ -1373,36 +1532,62 @@ int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const
         return RT_ERR_BAD_ARG;
     }
     if (n_rays == 0) return RT_OK;
+    std::vector<uint8_t> flags((size_t)n_rays);
+    int rc = list_pass(s, false, n_rays, origins, directions, max_hits, count_out, t_out, object_id_out, flags.data());
+    if (rc != RT_OK) return rc;
+    // rays whose list (or a CSG subtree's pending list) did not fit the per-lane arrays: again, with the lists in HBM
+    int cap = LIST_CAP;
+    std::vector<int64_t> todo;
+    for (int64_t i = 0; i < n_rays; ++i)
+        if (count_out[i] > cap || (flags[size_t(i)] & RT_FLAG_LIST_OVERFLOW)) todo.push_back(i);
+    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty(); ++round) {
+        if ((rc = ensure_arena(s, round)) != RT_OK) return rc;
+        cap = ARENA_ROUNDS[round].list_cap;
+        const size_t m = todo.size();
+        std::vector<double> o(m * 3), d(m * 3), tt(m * size_t(max_hits));
+        std::vector<int32_t> cnt(m), ids(m * size_t(max_hits));
+        std::vector<uint8_t> fl(m);
+        for (size_t j = 0; j < m; ++j)
+            for (int k = 0; k < 3; ++k) { o[3 * j + k] = origins[3 * todo[j] + k]; d[3 * j + k] = directions[3 * todo[j] + k]; }
+        if ((rc = list_pass(s, true, int64_t(m), o.data(), d.data(), max_hits, cnt.data(), tt.data(), ids.data(), fl.data())) != RT_OK) return rc;
+        std::vector<int64_t> still;
+        for (size_t j = 0; j < m; ++j) {
+            const int64_t i = todo[j];
+            count_out[i] = cnt[j];
+            std::memcpy(t_out + size_t(i) * max_hits, tt.data() + j * size_t(max_hits), size_t(max_hits) * sizeof(double));
+            std::memcpy(object_id_out + size_t(i) * max_hits, ids.data() + j * size_t(max_hits), size_t(max_hits) * sizeof(int32_t));
+            flags[size_t(i)] = fl[j];
+            if (cnt[j] > cap || (fl[j] & RT_FLAG_LIST_OVERFLOW)) still.push_back(i);
+        }
+        todo.swap(still);
+    }
+    if (!todo.empty()) {
+        rt_set_error("ray %lld has %d intersections (or more than %d pending inside one CSG subtree); the largest device list holds %d",
+                     (long long)todo[0], count_out[todo[0]], ARENA_ROUNDS[N_ARENA_ROUNDS - 1].csg_cap, cap);
+        return RT_ERR_OVERFLOW;
+    }
+    return RT_OK;
+}
+
+static int shadow_pass(rt_scene* s, bool big, int64_t n, const double* points, uint8_t* out, uint8_t* flags_host) {
     hipStream_t st = s->stream;
     int rc;
-    size_t rb = size_t(n_rays) * 3 * sizeof(double);
-    size_t lb = size_t(n_rays) * size_t(max_hits);
-    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->misc_a, size_t(n_rays) * sizeof(int32_t))) != RT_OK ||
-        (rc = grow(s->misc_b, lb * sizeof(double))) != RT_OK || (rc = grow(s->misc_c, lb * sizeof(int32_t))) != RT_OK)
-        return rc;
-    HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(s->misc_b.p, 0, lb * sizeof(double), st));
-    HIP_TRY(hipMemsetAsync(s->misc_c.p, 0, lb * sizeof(int32_t), st));
-    if (s->has_csg)
-        rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
-                         static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
-                         static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
-    else
-        rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, static_cast<const double*>(s->in_a.p),
-                         static_cast<const double*>(s->in_b.p), (int)max_hits, static_cast<int32_t*>(s->misc_a.p),
-                         static_cast<double*>(s->misc_b.p), static_cast<int32_t*>(s->misc_c.p));
+    const size_t rb = size_t(n) * 3 * sizeof(double), ob = size_t(n) * size_t(s->n_lights);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->misc_a, ob)) != RT_OK || (rc = grow(s->out_flags, size_t(n))) != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
+    const double* p = static_cast<const double*>(s->in_a.p);
+    uint8_t* o = static_cast<uint8_t*>(s->misc_a.p);
+    uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
+    s->big = big;
+    if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    else if (s->has_csg) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    else rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    s->big = false;
     if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(count_out, s->misc_a.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(t_out, s->misc_b.p, lb * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(object_id_out, s->misc_c.p, lb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out, o, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags_host, fl, size_t(n), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (int64_t i = 0; i < n_rays; ++i)
-        if (count_out[i] > LIST_CAP) {
-            rt_set_error("ray %lld has %d intersections; the device list holds %d", (long long)i, count_out[i], LIST_CAP);
-            return RT_ERR_OVERFLOW;
-        }
     return RT_OK;
 }
 
@@ -1410,21 +1595,33 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
     if (n_points < 0 || !points || !out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     if (n_points == 0 || s->n_lights == 0) return RT_OK;
-    hipStream_t st = s->stream;
-    int rc;
-    size_t rb = size_t(n_points) * 3 * sizeof(double), ob = size_t(n_points) * size_t(s->n_lights);
-    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->misc_a, ob)) != RT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
-    if (s->has_csg)
-        rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL>, chunks_for(n_points), s->ds, (long long)n_points,
-                         static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
-    else
-        rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n_points), s->ds, (long long)n_points,
-                         static_cast<const double*>(s->in_a.p), static_cast<uint8_t*>(s->misc_a.p));
+    std::vector<uint8_t> flags((size_t)n_points);
+    int rc = shadow_pass(s, false, n_points, points, out, flags.data());
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, s->misc_a.p, ob, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int64_t> todo;  // shadow rays through a CSG subtree with more pending intersections than the per-lane array holds
+    for (int64_t i = 0; i < n_points; ++i)
+        if (flags[size_t(i)] & RT_FLAG_LIST_OVERFLOW) todo.push_back(i);
+    const size_t nl = size_t(s->n_lights);
+    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty(); ++round) {
+        if ((rc = ensure_arena(s, round)) != RT_OK) return rc;
+        const size_t m = todo.size();
+        std::vector<double> p(m * 3);
+        std::vector<uint8_t> o(m * nl), fl(m);
+        for (size_t j = 0; j < m; ++j)
+            for (int k = 0; k < 3; ++k) p[3 * j + k] = points[3 * todo[j] + k];
+        if ((rc = shadow_pass(s, true, int64_t(m), p.data(), o.data(), fl.data())) != RT_OK) return rc;
+        std::vector<int64_t> still;
+        for (size_t j = 0; j < m; ++j) {
+            std::memcpy(out + size_t(todo[j]) * nl, o.data() + j * nl, nl);
+            if (fl[j] & RT_FLAG_LIST_OVERFLOW) still.push_back(todo[j]);
+        }
+        todo.swap(still);
+    }
+    if (!todo.empty()) {
+        rt_set_error("shadow ray of point %lld has more than %d intersections pending inside one CSG subtree", (long long)todo[0],
+                     ARENA_ROUNDS[N_ARENA_ROUNDS - 1].csg_cap);
+        return RT_ERR_OVERFLOW;
+    }
     return RT_OK;
 }
 

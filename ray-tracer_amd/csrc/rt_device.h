@@ -23,6 +23,7 @@ constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
+constexpr int CSG_DEPTH_BIG = 64;  // ... in the overflow (BIG) kernel variants, whose lists live in the HBM arena
 #ifndef RT_LIST_CAP
 #define RT_LIST_CAP 256
 #endif
@@ -77,6 +78,10 @@ struct DScene {
                                       //    itself (F14): the n1/n2 walk cannot be skipped at remaining == 0 (needs_walk)
     int32_t passive_mesh_tris;        // 1: every triangle of a mesh BVH is equal (Shape::eq) to no other node: WalkSink may drop
                                       //    all but the last of them below the hit (rt_kernels.hip.h)
+    // HBM arena of the BIG kernel variants (rt_kernels.hip.h: CsgScratch<true>, arena_list): one slab per lane
+    char* arena;
+    long long arena_lane_bytes;       // csg_cap * 28 + list_cap * 16
+    int32_t arena_csg_cap, arena_list_cap;
     int32_t* spill;                   // [BVH_STACK - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
     long long spill_lanes;
 };
@@ -106,6 +111,7 @@ enum Counter : int {
     CNT_NEXT,          // rays appended to the next level
     CNT_SHADOW_Q,      // entries of the level's shadow queue (= nodes that hit something)
     CNT_CONTAINER_Q,   // entries of the level's container queue (n1/n2 walks)
+    CNT_OVERFLOW,      // block 0 only: level-0 rays whose tree ran into a bounded list (RT_FLAG_LIST_OVERFLOW)
     // work of the instrumented build (rt_render_opts.want_counters), RT_WORK_COUNT rows per kernel class
     CNT_W_XFORMS,                                    // closest-hit part of k_trace for this level's rays
     CNT_WS_XFORMS = CNT_W_XFORMS + RT_WORK_COUNT,    // shadow rays of THIS level's hits (traced by the next k_trace)

@@ -218,8 +218,34 @@ struct ShortList {
     }
 };
 
-// stable sort by t == sort by (t, key): insertion sort on a short private list
+// In-place heapsort by (t, key) for the long lists of the BIG variants (insertion sort is quadratic; the order is total,
+// so stability does not matter).  `swap(a, b)` exchanges entries, `less(a, b)` compares them.
+template <class Less, class Swap>
+__device__ inline void heap_sort(int lo, int n, Less&& less, Swap&& swap) {
+    auto sift = [&](int root, int end) {
+        while (true) {
+            int child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && less(lo + child, lo + child + 1)) ++child;
+            if (!less(lo + root, lo + child)) break;
+            swap(lo + root, lo + child);
+            root = child;
+        }
+    };
+    for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+    for (int end = n - 1; end > 0; --end) {
+        swap(lo, lo + end);
+        sift(0, end);
+    }
+}
+
+// stable sort by t == sort by (t, key): insertion sort on a short private list (heapsort beyond 64 entries)
 __device__ inline void sort_list(double* t, int* key, int n) {
+    if (n > 64) {
+        heap_sort(0, n, [&](int a, int b) { return key_less(t[a], key[a], t[b], key[b]); },
+                  [&](int a, int b) { const double x = t[a]; t[a] = t[b]; t[b] = x; const int y = key[a]; key[a] = key[b]; key[b] = y; });
+        return;
+    }
     for (int i = 1; i < n; ++i) {
         double ti = t[i];
         int ki = key[i];
@@ -628,13 +654,48 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
 // Scene traversal == World::intersect_world (src/world.rs:46-55) without materialising the list: every
 // intersection the reference would list is handed to `sink` with its (t, key).
 
-struct CsgScratch {
+// The pending intersections of the CSG subtrees a ray is inside of.  Ordinary kernels keep them in per-lane private
+// arrays of CSG_CAP entries; a ray that needs more says so (RT_FLAG_LIST_OVERFLOW), and the host traces it again with
+// the BIG kernel variants (scene class bit SC_BIG), whose lists live in an HBM arena with run-time capacities
+// (DScene::arena*, one slab per lane of the — small — grid those variants are launched with).
+template <bool BIG>
+struct CsgScratch;
+template <>
+struct CsgScratch<false> {
     double t[CSG_CAP], u[CSG_CAP], v[CSG_CAP];
     int key[CSG_CAP];
     int seg[CSG_DEPTH];
     int n, depth;
     unsigned flags;
+    __device__ __forceinline__ void bind(const DScene&) {}
+    __device__ __forceinline__ int cap() const { return CSG_CAP; }
+    __device__ __forceinline__ int max_depth() const { return CSG_DEPTH; }
 };
+template <>
+struct CsgScratch<true> {
+    double *t, *u, *v;
+    int* key;
+    int seg[CSG_DEPTH_BIG];
+    int n, depth;
+    unsigned flags;
+    int cap_;
+    __device__ __forceinline__ void bind(const DScene& S) {
+        char* lane = S.arena + ((long long)blockIdx.x * TBLOCK + threadIdx.x) * S.arena_lane_bytes;
+        cap_ = S.arena_csg_cap;
+        t = reinterpret_cast<double*>(lane);
+        u = t + cap_;
+        v = u + cap_;
+        key = reinterpret_cast<int*>(v + cap_);
+    }
+    __device__ __forceinline__ int cap() const { return cap_; }
+    __device__ __forceinline__ int max_depth() const { return CSG_DEPTH_BIG; }
+};
+// the list part of a lane's arena slab (behind the CSG part): t[list_cap], key[list_cap], containers[list_cap]
+__device__ __forceinline__ char* arena_list(const DScene& S) {
+    return S.arena + ((long long)blockIdx.x * TBLOCK + threadIdx.x) * S.arena_lane_bytes + (long long)S.arena_csg_cap * 28;
+}
+
+
 
 __device__ __forceinline__ bool csg_allowed(int op, bool left_hit, bool inl, bool inr) {  // src/csg.rs:95-104
     switch (op) {
@@ -658,21 +719,22 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // with the whole wavefront executing.
 // SC = scene class: bit 0 the scene has CSG nodes, bit 1 its program has ITEM_CULL ranges (code for either is only
 // compiled into the kernels of scenes that need it).
-constexpr int SC_CSG = 1, SC_CULL = 2;
+constexpr int SC_CSG = 1, SC_CULL = 2, SC_BIG = 4;
 template <int SC, bool COUNT, class Sink>
 __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive) {
-    constexpr bool HAS_CSG = (SC & SC_CSG) != 0, HAS_CULL = (SC & SC_CULL) != 0;
-    CsgScratch* cs = nullptr;
-    CsgScratch cs_storage;
+    constexpr bool HAS_CSG = (SC & SC_CSG) != 0, HAS_CULL = (SC & SC_CULL) != 0, BIG = (SC & SC_BIG) != 0;
+    CsgScratch<BIG>* cs = nullptr;
+    CsgScratch<BIG> cs_storage;
     if (HAS_CSG) {
         cs = &cs_storage;
+        cs->bind(S);
         cs->n = 0;
         cs->depth = 0;
         cs->flags = 0;
     }
     auto out = [&](double t, int key, double u, double v, int uv) {
         if (HAS_CSG && cs->depth > 0) {
-            if (cs->n < CSG_CAP) {
+            if (cs->n < cs->cap()) {
                 int i = cs->n++;
                 cs->t[i] = t; cs->key[i] = key; cs->u[i] = u; cs->v[i] = v;
                 if (uv) cs->key[i] |= (1 << 30);
@@ -706,7 +768,7 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         ++i;
         if (it.type == ITEM_CSG_BEGIN) {
             if (HAS_CSG && on) {
-                if (cs->depth < CSG_DEPTH) cs->seg[cs->depth] = cs->n; else cs->flags |= RT_FLAG_LIST_OVERFLOW;
+                if (cs->depth < cs->max_depth()) cs->seg[cs->depth] = cs->n; else cs->flags |= RT_FLAG_LIST_OVERFLOW;
                 cs->depth++;
             }
             continue;
@@ -714,18 +776,30 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         if (it.type == ITEM_CSG_END) {
             if (HAS_CSG && on) {
                 cs->depth--;
-                int s0 = cs->depth < CSG_DEPTH ? cs->seg[cs->depth] : 0;
+                int s0 = cs->depth < cs->max_depth() ? cs->seg[cs->depth] : 0;
                 // sort the operand lists together (stable by t == by (t, key)), src/csg.rs:70-71
-                for (int a = s0 + 1; a < cs->n; ++a) {
-                    double ta = cs->t[a], ua = cs->u[a], va = cs->v[a];
-                    int ka = cs->key[a];
-                    if (ta != ta) cs->flags |= RT_FLAG_NAN_T;
-                    int b = a - 1;
-                    while (b >= s0 && key_less(ta, ka & ~(1 << 30), cs->t[b], cs->key[b] & ~(1 << 30))) {
-                        cs->t[b + 1] = cs->t[b]; cs->u[b + 1] = cs->u[b]; cs->v[b + 1] = cs->v[b]; cs->key[b + 1] = cs->key[b];
-                        --b;
+                for (int a = s0; a < cs->n; ++a)
+                    if (cs->t[a] != cs->t[a]) cs->flags |= RT_FLAG_NAN_T;
+                if (BIG && cs->n - s0 > 48) {
+                    heap_sort(s0, cs->n - s0,
+                              [&](int a, int b) { return key_less(cs->t[a], cs->key[a] & ~(1 << 30), cs->t[b], cs->key[b] & ~(1 << 30)); },
+                              [&](int a, int b) {
+                                  const double ta = cs->t[a], ua = cs->u[a], va = cs->v[a];
+                                  const int ka = cs->key[a];
+                                  cs->t[a] = cs->t[b]; cs->u[a] = cs->u[b]; cs->v[a] = cs->v[b]; cs->key[a] = cs->key[b];
+                                  cs->t[b] = ta; cs->u[b] = ua; cs->v[b] = va; cs->key[b] = ka;
+                              });
+                } else {
+                    for (int a = s0 + 1; a < cs->n; ++a) {
+                        double ta = cs->t[a], ua = cs->u[a], va = cs->v[a];
+                        int ka = cs->key[a];
+                        int b = a - 1;
+                        while (b >= s0 && key_less(ta, ka & ~(1 << 30), cs->t[b], cs->key[b] & ~(1 << 30))) {
+                            cs->t[b + 1] = cs->t[b]; cs->u[b + 1] = cs->u[b]; cs->v[b + 1] = cs->v[b]; cs->key[b + 1] = cs->key[b];
+                            --b;
+                        }
+                        cs->t[b + 1] = ta; cs->u[b + 1] = ua; cs->v[b + 1] = va; cs->key[b + 1] = ka;
                     }
-                    cs->t[b + 1] = ta; cs->u[b + 1] = ua; cs->v[b + 1] = va; cs->key[b + 1] = ka;
                 }
                 // filter_intersections, src/csg.rs:106-126
                 bool inl = false, inr = false;
@@ -1213,15 +1287,24 @@ __device__ __forceinline__ bool is_shadowed(const DScene& S, const TravMem& M, V
 template <int SC, bool COUNT>
 __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M, V3 o, V3 d, double hit_t, int hit_node, Work& w,
                                                double& n1_out, double& n2_out, unsigned& flags, bool alive) {
-    double lt[LIST_CAP];
-    int lk[LIST_CAP];
+    constexpr bool BIG = (SC & SC_BIG) != 0;
+    double lt_private[BIG ? 1 : LIST_CAP];
+    int lk_private[BIG ? 1 : LIST_CAP];
+    double* lt = lt_private;
+    int* lk = lk_private;
+    int list_cap = LIST_CAP;
+    if (BIG) {
+        list_cap = S.arena_list_cap;
+        lt = reinterpret_cast<double*>(arena_list(S));
+        lk = reinterpret_cast<int*>(lt + list_cap);
+    }
     WalkSink sink;
-    sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = hit_t; sink.flags = 0;
+    sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = list_cap; sink.limit = hit_t; sink.flags = 0;
     sink.below_t = -INFINITY; sink.below_key = -1; sink.hit_node = hit_node; sink.passive = S.passive_mesh_tris != 0;
     traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
     sink.finish();
     flags |= sink.flags;
-    const int n = sink.n < LIST_CAP ? sink.n : LIST_CAP;
+    const int n = sink.n < list_cap ? sink.n : list_cap;
     const int hit_cls = alive ? S.node_eq_class[hit_node] : -1;
     double n1 = 0., n2 = 0.;
     const bool is_short = n <= SHORT_LIST;
@@ -1286,7 +1369,9 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
         }
     } else {
         sort_list(lt, lk, n);
-        int containers[CONTAINER_CAP];
+        int containers_private[BIG ? 1 : CONTAINER_CAP];
+        int* containers = BIG ? lk + list_cap : containers_private;
+        const int container_cap = BIG ? list_cap : CONTAINER_CAP;
         int nc = 0;
         for (int i = 0; i < n; ++i) {
             int node = lk[i] >> 2;
@@ -1301,7 +1386,7 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
             if (found >= 0) {
                 for (int k = found; k + 1 < nc; ++k) containers[k] = containers[k + 1];
                 --nc;
-            } else if (nc < CONTAINER_CAP) {
+            } else if (nc < container_cap) {
                 containers[nc++] = node;
             } else {
                 flags |= RT_FLAG_LIST_OVERFLOW;
@@ -1659,13 +1744,15 @@ __global__ __launch_bounds__(BLOCK) void k_spawn(Level L, Level N, long long n_c
 // Bottom-up: shade_hit for every node of one level (src/world.rs:57-79) == Material::lighting over the lights (the
 // shadow flags are in by now), schlick, and the blend with the children's resolved colours in the reference's own
 // operand order; color_at's miss case -> BLACK.  Surface colour, coefficients and reflectance never leave registers.
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next,
+                                                 unsigned long long* overflow_count) {
     const long long n = level_count(n_cap, n_dev);
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const int key = L.hkey[i];
     if (key < 0) {  // miss -> BLACK
         L.cr[i] = 0.; L.cg[i] = 0.; L.cb[i] = 0.;
+        if (overflow_count && (L.flags[i] & RT_FLAG_LIST_OVERFLOW)) atomicAdd(overflow_count, 1ull);
         return;
     }
     const int stage = L.mode[i];
@@ -1704,6 +1791,28 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, lon
     }
     L.cr[i] = out.x; L.cg[i] = out.y; L.cb[i] = out.z;
     L.flags[i] = (uint8_t)flags;
+    // a level-0 ray whose tree ran into a bounded list: the host traces those again with the BIG variants
+    if (overflow_count && (flags & RT_FLAG_LIST_OVERFLOW)) atomicAdd(overflow_count, 1ull);
+}
+
+// Level-0 rays whose resolved flags carry RT_FLAG_LIST_OVERFLOW: their indices (any order) and rays, for the fix-up pass.
+__global__ __launch_bounds__(BLOCK) void k_collect_overflow(Level L, long long n, unsigned long long* cursor, int32_t* index_out,
+                                                            Level F) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || !(L.flags[i] & RT_FLAG_LIST_OVERFLOW) || is_dead_ray(L.ox[i])) return;
+    const long long j = (long long)atomicAdd(cursor, 1ull);
+    index_out[j] = (int32_t)i;
+    F.ox[j] = L.ox[i]; F.oy[j] = L.oy[i]; F.oz[j] = L.oz[i];
+    F.dx[j] = L.dx[i]; F.dy[j] = L.dy[i]; F.dz[j] = L.dz[i];
+}
+// ... and their re-traced results back into place
+__global__ __launch_bounds__(BLOCK) void k_patch_overflow(Level L, Level F, long long n_fix, const int32_t* __restrict__ index) {
+    const long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_fix) return;
+    const long long i = index[j];
+    L.cr[i] = F.cr[j]; L.cg[i] = F.cg[j]; L.cb[i] = F.cb[j];
+    L.hkey[i] = F.hkey[j];
+    L.flags[i] = F.flags[j];
 }
 
 // Kernel: level-0 colours -> caller's buffers, interleaved RGB.  frame == 0: shard-local order; frame == 1:
@@ -1764,16 +1873,25 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_all(CameraParams c, long lon
 template <int SC>
 __global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const double* __restrict__ origins,
                                                  const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
-                                                 int32_t* id_out) {
+                                                 int32_t* id_out, uint8_t* flags_out) {
+    constexpr bool BIG = (SC & SC_BIG) != 0;
     Feed feed;
     const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
     for (long long c = feed.next(); c >= 0; c = feed.next()) {
         const long long i = c * 64 + (threadIdx.x & 63);
         const bool alive = i < n;
-        double lt[LIST_CAP];
-        int lk[LIST_CAP];
+        double lt_private[BIG ? 1 : LIST_CAP];
+        int lk_private[BIG ? 1 : LIST_CAP];
+        double* lt = lt_private;
+        int* lk = lk_private;
+        int list_cap = LIST_CAP;
+        if (BIG) {
+            list_cap = S.arena_list_cap;
+            lt = reinterpret_cast<double*>(arena_list(S));
+            lk = reinterpret_cast<int*>(lt + list_cap);
+        }
         ListSink sink;
-        sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = LIST_CAP; sink.limit = INFINITY; sink.flags = 0;
+        sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = list_cap; sink.limit = INFINITY; sink.flags = 0;
         Work w = {};
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (alive) {
@@ -1782,9 +1900,10 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const
         }
         traverse<SC, false>(S, M, o, d, sink, w, alive);
         if (!alive) continue;
-        int m = sink.n < LIST_CAP ? sink.n : LIST_CAP;
+        int m = sink.n < list_cap ? sink.n : list_cap;
         sort_list(lt, lk, m);
         count[i] = sink.n;
+        flags_out[i] = (uint8_t)sink.flags;
         for (int k = 0; k < m && k < max_hits; ++k) {
             t_out[i * max_hits + k] = lt[k];
             id_out[i * max_hits + k] = S.node_object_id[lk[k] >> 2];
@@ -1794,7 +1913,8 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const
 
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
 template <int SC>
-__global__ __launch_bounds__(TBLOCK, 4) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out) {
+__global__ __launch_bounds__(TBLOCK, 4) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out,
+                                                          uint8_t* flags_out) {
     Feed feed;
     const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
     for (long long c = feed.next(); c >= 0; c = feed.next()) {
@@ -1807,6 +1927,7 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_shadow_points(DScene S, long long
             bool sh = is_shadowed<SC, false>(S, M, p, l, w, flags, alive);
             if (alive) out[i * S.n_lights + l] = sh ? 1 : 0;
         }
+        if (alive) flags_out[i] = (uint8_t)flags;
     }
 }
 
