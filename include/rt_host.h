@@ -82,7 +82,8 @@ int rth_world_create(const int* shapes, int n_shapes, const double* light_positi
 void rth_world_free(int world);
 /* Flattened tables for the hot path; owned by the world handle, valid until rth_world_free. */
 const rt_scene_desc* rth_world_flatten(int world);
-/* Device copy (rt_scene_create on first use); owned by the world handle. */
+/* Device copy on `device` (rt_scene_create on first use, one per device); owned by the world handle and valid until
+ * rth_world_free — asking for another device does not invalidate a handle given out earlier. */
 rt_scene* rth_world_scene(int world, int device);
 
 /* ---- src/camera.rs:21-35: Camera::new + transform -> descriptor for rt_render ---- */

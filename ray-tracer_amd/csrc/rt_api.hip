@@ -991,6 +991,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->ds.n_nodes = d.n_nodes;
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
+    s->ds.cull_reach = prog.cull_reach;
     s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));
     s->trav_lds_bytes = prog.bvh.empty() ? 0 : size_t(s->ds.n_lds) * sizeof(BvhNode) + size_t(LDS_STACK) * TBLOCK * sizeof(int);
     {

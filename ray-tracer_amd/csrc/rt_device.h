@@ -78,6 +78,7 @@ struct DScene {
                                       //    itself (F14): the n1/n2 walk cannot be skipped at remaining == 0 (needs_walk)
     int32_t passive_mesh_tris;        // 1: every triangle of a mesh BVH is equal (Shape::eq) to no other node: WalkSink may drop
                                       //    all but the last of them below the hit (rt_kernels.hip.h)
+    double cull_reach;                // ITEM_CULL ranges are trusted for rays whose origin has max |coordinate| below this
     // HBM arena of the BIG kernel variants (rt_kernels.hip.h: CsgScratch<true>, arena_list): one slab per lane
     char* arena;
     long long arena_lane_bytes;       // csg_cap * 28 + list_cap * 16

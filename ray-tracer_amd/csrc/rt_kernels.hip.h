@@ -749,6 +749,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         if (HAS_CSG && cs->depth > 0) out(t, key, u, v, uv);
         else sink.emit_mesh(t, key, u, v, uv);
     };
+    // From very far away the reference's quadratics report tangent hits outside the padded bounds of the ITEM_CULL
+    // ranges (rt_program.cpp: WBox::reach): a ray that starts beyond the scene's reach is never culled by them.
+    const bool cull_trusted = HAS_CULL && fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) < S.cull_reach;
     const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
     const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
     const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);
@@ -842,7 +845,7 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                 const V3 inv_world = mk(slab_rcp(rd.x), slab_rcp(rd.y), slab_rcp(rd.z));
                 double tnear;
                 bump<COUNT>(w.box);
-                if (!bvh_box(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], ro, inv_world, sink.lo(), sink.hi(), tnear)) until = it.skip;
+                if (cull_trusted && !bvh_box(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], ro, inv_world, sink.lo(), sink.hi(), tnear)) until = it.skip;
             }
             if (__ballot(i >= until) == 0) i = wave_min_i32(until);  // nobody needs the range: jump, uniformly
             continue;

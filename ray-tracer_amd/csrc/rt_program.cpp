@@ -404,8 +404,14 @@ struct Compiler {
     struct WBox {
         double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
         bool bounded = true;  // false: unbounded or not computable — never culled
+        // How far (L-infinity, world units) a ray's origin may be from anything in the box for the box to be trusted: the
+        // reference's quadratics lose ~1.1e-16 |o_obj|^2 in object space (c = o.o - 1, b^2 - 4ac), so from ~3e4 object
+        // radii away it reports tangent hits further outside the unit shape than the 1e-7 padding of the boxes.  Each
+        // leaf allows 1e3 object units (error ~1e-10); 1 / prod ||inverse||_F bounds the chain's smallest scale from below.
+        double reach = INF;
         void add(const WBox& o) {
             bounded = bounded && o.bounded;
+            reach = std::min(reach, o.reach);
             for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); }
         }
     };
@@ -429,9 +435,22 @@ struct Compiler {
         }
         return forward_cache.emplace(x, out).first->second;
     }
-    // object-space box -> world, through the non-identity transforms `chain` (outermost first)
-    WBox to_world(const double* lo, const double* hi, const std::vector<int32_t>& chain) {
+    double chain_min_scale(const std::vector<int32_t>& chain) {  // lower bound of the smallest singular value of the forward chain
+        double prod = 1.;
+        for (int32_t x : chain) {
+            const double* m = d.xform_inverse + size_t(x) * 16;
+            double f2 = 0.;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) f2 += m[4 * r + c] * m[4 * r + c];
+            prod *= std::sqrt(f2);
+        }
+        return prod > 0. && std::isfinite(prod) ? 1. / prod : 0.;
+    }
+    // object-space box -> world, through the non-identity transforms `chain` (outermost first); `size`: the object-space
+    // length the leaf's arithmetic error is relative to (1 for the unit shapes)
+    WBox to_world(const double* lo, const double* hi, const std::vector<int32_t>& chain, double size = 1.) {
         WBox w;
+        w.reach = 1e3 * size * chain_min_scale(chain) / std::sqrt(3.);
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) { w.bounded = false; return w; }
         double pts[8][3];
@@ -493,7 +512,9 @@ struct Compiler {
                     lo[k] = std::min(a, std::min(b, c));
                     hi[k] = std::max(a, std::max(b, c));
                 }
-                return to_world(lo, hi, chain);
+                // Moller-Trumbore's error is linear in the distance (u, v lose ~1e-16 |o| / edge, i.e. ~1e-16 |o| laterally),
+                // against a padding of 1e-7 of the coordinates: trusted up to 1e6 extents
+                return to_world(lo, hi, chain, 1e3 * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])));
             }
             case RT_GROUP: {
                 // children without a transform of their own share this chain: unite them in object space first
@@ -513,7 +534,8 @@ struct Compiler {
                         w.add(world_box(c, chain));
                     }
                 }
-                if (any_plain) w.add(to_world(lo, hi, chain));
+                // (triangles: see RT_TRIANGLE above; the mesh's own extent is the scale its padding is relative to)
+                if (any_plain) w.add(to_world(lo, hi, chain, 1e3 * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]))));
                 return w;
             }
             default: {  // CSG: whatever survives the filter lies on an operand
@@ -550,6 +572,12 @@ struct Compiler {
                 b[k] = all.lo[k] - pad;
                 b[3 + k] = all.hi[k] + pad;
             }
+            // the ranges are trusted only for rays that start within `reach` (L-infinity) of everything in them: folded
+            // into one bound on the origin's largest |coordinate| for the whole program
+            double far_plane = 0.;
+            for (int k = 0; k < 6; ++k) far_plane = std::max(far_plane, std::fabs(b[k]));
+            const double r = std::max(0., all.reach - far_plane);
+            p.cull_reach = p.has_cull ? std::min(p.cull_reach, r) : r;
             cull = int32_t(p.items.size());
             p.items.push_back(it);
             p.has_cull = true;

@@ -81,6 +81,7 @@ struct Program {
     bool has_csg = false;
     int32_t meshes_built_on_gpu = 0;   // meshes whose tree topology came from rt_lbvh.hip
     bool has_cull = false;             // the program has ITEM_CULL ranges
+    double cull_reach = 0.;            // ... trusted for rays whose origin has max |coordinate| below this (WBox::reach)
     bool has_smooth = false;
     bool all_cast_shadow = true;
     int32_t max_chain = 0;

@@ -625,9 +625,9 @@ World World::default_world() {  // src/world.rs:20-39
 World::~World() { invalidate(); }
 
 void World::invalidate() const {
-    if (scene_) rt_scene_destroy(scene_);
-    scene_ = nullptr;
-    scene_device_ = -1;
+    for (auto& kv : scenes_)
+        if (kv.second) rt_scene_destroy(kv.second);
+    scenes_.clear();
 }
 
 static void check_rt(int rc) {
@@ -635,13 +635,14 @@ static void check_rt(int rc) {
 }
 
 rt_scene* World::device_scene(int device) const {
-    if (scene_ && scene_device_ == device) return scene_;
-    invalidate();
+    auto it = scenes_.find(device);
+    if (it != scenes_.end()) return it->second;
     FlatScene flat = flatten();
     rt_scene_desc d = flat.desc();
-    check_rt(rt_scene_create(&d, device, &scene_));
-    scene_device_ = device;
-    return scene_;
+    rt_scene* scene = nullptr;
+    check_rt(rt_scene_create(&d, device, &scene));
+    scenes_[device] = scene;
+    return scene;
 }
 
 std::vector<Intersection> World::intersect_world(const Ray& ray) const {  // src/world.rs:46-55

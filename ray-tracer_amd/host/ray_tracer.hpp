@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <limits>
 #include <memory>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -342,13 +343,14 @@ public:
     std::vector<Intersection> intersect_world(const Ray& ray) const;
     Color color_at(const Ray& ray, int remaining) const;
     std::vector<bool> is_shadowed(const Tuple& point) const;
-    // Handle of the device copy of this world (built on first use; invalidate() after mutating the world).
+    // Handle of the device copy of this world on `device` (built on first use, one per device, all kept until
+    // invalidate() — call that after mutating the world — or destruction: a handle given out stays valid when another
+    // device is asked for).
     rt_scene* device_scene(int device = 0) const;
     void invalidate() const;
 
 private:
-    mutable rt_scene* scene_ = nullptr;
-    mutable int scene_device_ = -1;
+    mutable std::map<int, rt_scene*> scenes_;
 };
 
 // ---------------------------------------------------------------- camera.rs

@@ -35,15 +35,44 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.origin:
         return
     bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(bundled):
-        try:
-            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    if not os.path.exists(bundled):
+        return
+    # Bind to torch's copy only if it is the runtime generation this library was linked against (its DT_NEEDED names
+    # libamdhip64.so.<major>): a bundled runtime of another major version would leave two runtimes in the process after
+    # all, or bind the library to an ABI it was not built for.
+    want, have = _needed_hip_major(LIB_PATH), _needed_hip_major(bundled)   # no HIP call: nothing touches the GPU at import
+    global HIP_RUNTIME_BOUND
+    if want is not None and have is not None and have != want:
+        import warnings
+        warnings.warn(f"rt_amd: torch bundles libamdhip64.so.{have}, libraytracer_amd.so was linked against libamdhip64.so.{want}: "
+                      "not preloading it (the library binds the system runtime; import torch FIRST if both must share one process)")
+        return
+    try:
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        import warnings
+        warnings.warn(f"rt_amd: could not preload torch's HIP runtime ({e}); the system runtime is used")
+        return
+    HIP_RUNTIME_BOUND = f"{bundled} (soname libamdhip64.so.{have})"
 
 
+def _needed_hip_major(path):
+    """Major version in the file's DT_NEEDED / DT_SONAME text for libamdhip64 (None if it cannot be read)."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"libamdhip64\.so\.(\d+)", f.read())
+        return int(m.group(1)) if m else None
+    except OSError:
+        return None
+
+
+HIP_RUNTIME_BOUND = "system (the library's own DT_NEEDED)"
 _share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
+if os.environ.get("RT_AMD_VERBOSE"):
+    import sys as _sys
+    print(f"rt_amd: HIP runtime bound: {HIP_RUNTIME_BOUND}", file=_sys.stderr)
 
 EPSILON = 0.00001
 DEFAULT_RECURSION = 5

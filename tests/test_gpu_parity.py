@@ -561,6 +561,36 @@ def test_passive_mesh_triangles_in_the_n1_n2_walk_change_nothing(monkeypatch):
         assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
 
 
+def test_cull_ranges_are_not_trusted_from_very_far_away():
+    """from ~1e5 radii away the reference's quadratic (c = o.o - 1, b^2 - 4ac) reports tangent hits a few 1e-7
+    outside the unit sphere, further than the padding of the world-space cull boxes.  Rays aimed at the silhouette
+    +-1e-6 of small spheres in a world of eight bounded objects, from 1e5 away: lists equal to the oracle's."""
+    w = World()
+    w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
+    centres = [(2. * k - 7., 0.3 * k, 1.5 * (k % 3)) for k in range(8)]
+    for k, c in enumerate(centres):
+        sh = Shape.sphere() if k % 2 == 0 else Shape.cylinder().set_minimum(-1.).set_maximum(1.).set_closed(True)
+        w.objects.append(sh.set_transform(translate(*c)))
+    rng = np.random.default_rng(3)
+    o, d = [], []
+    for c in centres:
+        for _ in range(400):
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            origin = np.array(c) + 1e5 * u
+            v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+            target = np.array(c) + v * (1. + rng.uniform(-1e-6, 1e-6))     # a point on the silhouette seen from `origin`
+            dirn = target - origin
+            o.append(origin); d.append(dirn / np.linalg.norm(dirn))
+    o, d = np.array(o), np.array(d)
+    gc, gt, gi = w.intersect_world_batch(o, d, 16)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 16)
+    assert (oc > 0).sum() > 200 and (oc == 0).sum() > 200          # the sample straddles the silhouettes
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    g_rgb, g_id, _ = w.color_at_batch(o, d, 2)
+    o_rgb, o_id, _ = ob.color_at_batch(w, o, d, 2)
+    assert np.array_equal(g_id, o_id) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+
+
 def test_gpu_built_bvh_changes_nothing(monkeypatch):
     """RT_AMD_DEVICE_BVH=1: meshes of 1024+ triangles take their tree topology from the GPU (Morton sort + binary radix
     tree, csrc/rt_lbvh.hip).  A BVH only decides which triangles get tested: renders are bit-identical to those with the
