@@ -108,6 +108,10 @@ struct ClosestSink {
         stop_below = -INFINITY;
     }
     static constexpr bool FAR_FIRST = false;
+    // A triangle repeated under several nodes (MeshTri::smooth bits 1.., rt_program.cpp: build_mesh) is listed by the
+    // reference once per node, all with the same t: a minimum over (t, key) only ever keeps the lowest node, which is
+    // the one the BVH leaf carries, so this sink has no use for the repeats.
+    static constexpr bool WANTS_DUPS = false;
     __device__ __forceinline__ bool done() const { return best_t < stop_below; }
     __device__ __forceinline__ double lo() const { return NEED_FIRST ? -INFINITY : 0.; }
     __device__ __forceinline__ double lo_mesh() const { return lo(); }
@@ -127,6 +131,7 @@ struct ClosestSink {
 // Everything with t <= limit or near_eq(t, limit), kept as an unsorted bounded list (sorted by the caller).
 struct ListSink {
     static constexpr bool FAR_FIRST = false;
+    static constexpr bool WANTS_DUPS = true;
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ double lo_mesh() const { return lo(); }
     __device__ __forceinline__ void emit_mesh(double tt, int k, double u, double v, int uv) { emit(tt, k, u, v, uv); }
@@ -158,6 +163,7 @@ struct ListSink {
 // line into a pruned search (boxes that end below the best entry so far are skipped, far children first).
 struct WalkSink {
     static constexpr bool FAR_FIRST = true;
+    static constexpr bool WANTS_DUPS = true;
     __device__ __forceinline__ bool done() const { return false; }
     double* t;    // [LIST_CAP], private
     int* key;
@@ -631,8 +637,9 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 const TriHit hb = tri_eval<COUNT>(o, d, tb.p1, tb.e1, tb.e2, two, w);
                 if (ha.ok) e(ha.t, ta.node * 4, ha.u, ha.v, ta.smooth & 1);
                 if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth & 1);
-                // a hit on a repeated triangle counts once per node that carries it (rt_program.cpp: build_mesh)
-                if ((ha.ok && (ta.smooth >> 1)) || (hb.ok && (tb.smooth >> 1))) {
+                // a hit on a repeated triangle counts once per node that carries it (rt_program.cpp: build_mesh) — for sinks
+                // that keep lists, and inside CSG subtrees, whose filter toggles on every entry
+                if ((Sink::WANTS_DUPS || full_line) && ((ha.ok && (ta.smooth >> 1)) || (hb.ok && (tb.smooth >> 1)))) {
                     if (ha.ok && (ta.smooth >> 1)) {
                         const int* __restrict__ dl = S.mesh_dups + (ta.smooth >> 1) - 1;
                         for (int j = 1, c = dl[0]; j <= c; ++j) e(ha.t, dl[j] * 4, ha.u, ha.v, ta.smooth & 1);
