@@ -253,7 +253,14 @@ def main():
         dom = max(("k_trace", "k_walk"), key=lambda k: ms[k])
         n_launch = max(launches[dom], 1)
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        # PMC-measured HBM traffic of the profiled workloads (scripts/pmc_collect.sh, committed): the headline frame and
+        # C5 at the survey's scale; any other workload has no measurement and reports null
+        pmc_name = None
+        if args.scene == "teapot" and (args.width, args.height, args.depth) == (1920, 1080, 5):
+            pmc_name = "pmc_traffic.json"
+        elif args.scene == "grid" and (args.grid, args.width, args.height, args.depth) == (13, 7680, 4320, 8):
+            pmc_name = "r02_pmc_traffic_c5_grid13.json"
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name or "none")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
@@ -268,8 +275,8 @@ def main():
                               "the same launch schedule as the timed frames (plain enqueue where the timed frames replay "
                               "it as one HIP graph), no host wait between launches" % n_ev,
                     "flops_source": "work counters of one instrumented frame (want_counters=1) x SURVEY 8(d) constants",
-                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; "
-                                      "not collected in this run)",
+                    "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                       "committed; not collected in this run)" % pmc_name) if pmc is not None else None,
                     "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
