@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_low", "mixed", "book", "grid"])
     ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the second workload (C5 grid 4 at 8K) reported for the scaling sweep")
     ap.add_argument("--cpu-stride", type=int, default=12)
     args = ap.parse_args()
 
@@ -130,70 +131,87 @@ def main():
 
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
                 "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=args.grid)}
-    w, cam = builders[args.scene](args.width, args.height)
-    scene = w.scene(local_rank)          # flatten + upload + BVH build: outside the timed region
-    cd = cam.desc()
-    n_local = int(rt.lib.rt_shard_pixel_count(C.byref(cd), rank, world))
-    counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, world)) for r in range(world)]
-    n_max = max(counts)
-    # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
-    # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
-    # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
-    shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 0)]
-    gather_done = [None, None]
-    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-    # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
-    gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
-    gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
-    opts = rt.RenderOpts(max_depth=args.depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
-    torch_stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
-    state = {"k": 0}
 
-    def step(stats=None):
-        if world == 1:
-            # one GPU: Camera::render straight into the row-major frame in HBM (rt_render_frame), one blocking call
-            rc = rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None,
+    def make_job(w, cam, depth, width, height):
+        """The per-frame step of one workload on this rank: scene resident, buffers allocated, nothing timed yet."""
+        scene = w.scene(local_rank)          # flatten + upload + BVH build: outside the timed region
+        cd = cam.desc()
+        counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, world)) for r in range(world)]
+        n_max = max(counts)
+        # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
+        # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
+        # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
+        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 0)]
+        gather_done = [None, None]
+        frame = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+        # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
+        gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+        gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
+        opts = rt.RenderOpts(max_depth=depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
+        torch_stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
+        state = {"k": 0}
+
+        def step(stats=None):
+            if world == 1:
+                # one GPU: Camera::render straight into the row-major frame in HBM (rt_render_frame), one blocking call
+                rc = rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None,
+                                            C.byref(stats) if stats is not None else None)
+                if rc < 0:
+                    raise RuntimeError(rt.last_error())
+                return
+            b = state["k"] & 1
+            state["k"] += 1
+            if gather_done[b] is not None:
+                gather_done[b].synchronize()          # the gather that read this buffer two frames ago
+            # returns when the shard is complete in HBM (the library waits once per frame for its ray counters)
+            rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None,
                                         C.byref(stats) if stats is not None else None)
             if rc < 0:
                 raise RuntimeError(rt.last_error())
-            return
-        b = state["k"] & 1
-        state["k"] += 1
-        if gather_done[b] is not None:
-            gather_done[b].synchronize()          # the gather that read this buffer two frames ago
-        # returns when the shard is complete in HBM (the library waits once per frame for its ray counters)
-        rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None,
-                                    C.byref(stats) if stats is not None else None)
-        if rc < 0:
-            raise RuntimeError(rt.last_error())
-        dist.gather(shards[b], gathered, dst=0)   # RCCL gather over xGMI: no reduction, peers -> root; enqueued, not waited for
-        if rank == 0:                             # stream-ordered behind the gather on torch's stream
-            rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None,
-                                            C.c_void_p(torch_stream))
-            if rc < 0:
-                raise RuntimeError(rt.last_error())
-        ev = torch.cuda.Event()
-        ev.record()
-        gather_done[b] = ev
+            dist.gather(shards[b], gathered, dst=0)   # RCCL gather over xGMI: no reduction, peers -> root; enqueued, not waited for
+            if rank == 0:                             # stream-ordered behind the gather on torch's stream
+                rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None,
+                                                C.c_void_p(torch_stream))
+                if rc < 0:
+                    raise RuntimeError(rt.last_error())
+            ev = torch.cuda.Event()
+            ev.record()
+            gather_done[b] = ev
+
+        return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, gathered_all)}
+
+    def timed(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks, in ms per step."""
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) / steps * 1e3
+
+    def ray_counts(step):
+        st = rt.Stats()
+        step(st)
+        local = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes],
+                             dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(local)
+        return st, [int(x) for x in local.tolist()]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
-    ms_per_step = elapsed / args.steps * 1e3
+    w, cam = builders[args.scene](args.width, args.height)
+    job = make_job(w, cam, args.depth, args.width, args.height)
+    step, scene, cd, opts = job["step"], job["scene"], job["cd"], job["opts"]
+    ms_per_step = timed(step, args.steps, args.warmup)
 
     # ---- SURVEY 8(d)'s literal metric, reported next to `value`: rt_render = the same frame with HOST output buffers
     # (one 49.8 MB D2H copy of the f64 frame at 1080p included).  Never `value`: that is the HBM-resident rate.
@@ -211,8 +229,7 @@ def main():
         host_ms = (time.perf_counter() - t0) / n_host * 1e3
 
     # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
-    st = rt.Stats()
-    step(st)
+    st, rays = ray_counts(step)
     n_ev = 5
     ev = {"ms_trace": 0.0, "ms_collect": 0.0, "ms_shade": 0.0, "ms_resolve": 0.0, "ms_total": 0.0}
     for _ in range(n_ev):
@@ -224,12 +241,23 @@ def main():
     sc = rt.Stats()
     step(sc)
     opts.want_counters = 0
-    rays_local = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes],
-                              dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(rays_local)
-    rays = [int(x) for x in rays_local.tolist()]
     total_rays = sum(rays[:4])
+
+    # ---- second workload, for the scaling sweep (the driver runs this file at N = 1, 2, 4, 8 with default arguments):
+    # a 1.8 ms frame cannot scale across GPUs (launch floors and the gather dominate), C5 can.  Reported beside the
+    # headline, never as `value`: 4 x 4 instanced teapots (101,120 triangles), 7680x4320, depth 8, same tile sharding.
+    c5 = None
+    if args.scene == "teapot" and not args.no_c5:
+        barrier()
+        del job, step
+        w5, cam5 = scenes.instanced_grid(7680, 4320, grid=4)
+        job5 = make_job(w5, cam5, 8, 7680, 4320)
+        ms5 = timed(job5["step"], 5, 2)
+        _, rays5 = ray_counts(job5["step"])
+        c5 = {"workload": "configs[4] geometry at grid 4: 16 instanced teapots (101,120 triangles) + floor, 7680x4320, depth 8",
+              "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+              "steps": 5, "warmup": 2, "rays_per_frame": sum(rays5[:4]), "n_gpus": world}
+        del job5
 
     if rank == 0:
         n_lights = len(w.lights)
@@ -328,7 +356,7 @@ def main():
                    "ms_per_frame": round(host_ms, 4), "Mrays_s": round(total_rays / (host_ms * 1e-3) / 1e6, 3),
                    "what": "rt_render: the same frame into a HOST f64 buffer, D2H copy of %.1f MB included (SURVEY 8(d)'s "
                            "wording of the metric; PCIe-inclusive, so never `value`)" % (args.height * args.width * 24 / 1e6)},
-               "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
+               "c5_grid4_8k": c5, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
                "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
