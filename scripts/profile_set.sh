@@ -12,6 +12,7 @@ rm -rf $root/gpurun_out/${tag}_prof
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --no-cpu-baseline --no-c5 > $root/gpurun_out/${tag}_bench_under_rocprof.json 2> $root/gpurun_out/${tag}_prof.err
 cd $root
 bash scripts/pmc_collect.sh $tag 1920 1080 --steps 2 --warmup 1 --no-cpu-baseline --no-c5
+cp gpurun_out/pmc_${tag}.json profiles/pmc_traffic.json   # what the bench line below quotes as roofline.traffic
 timeout -k 10 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 bash scripts/all_configs.sh
 find gpurun_out/${tag}_prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/${tag}_kernel_stats.csv
