@@ -62,7 +62,8 @@ def _cpu_band(job):
     import oracle_bridge as ob
     import scenes
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
-                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=grid)}
+                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=grid),
+                "teapot_smooth": lambda wd, ht: scenes.teapot_scene(wd, ht, obj_text=scenes.smooth_teapot_obj())}
     w, cam = builders[scene](width, height)
     t0 = time.perf_counter()
     img = ob.render(w, cam, depth, stride=stride, rows=(y0, y1))
@@ -96,7 +97,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
-    ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_low", "mixed", "book", "grid"])
+    ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_smooth", "teapot_low", "mixed", "book", "grid"])
     ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the second workload (C5 grid 4 at 8K) reported for the scaling sweep")
@@ -130,7 +131,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
-                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=args.grid)}
+                "book": scenes.book_world, "grid": lambda wd, ht: scenes.instanced_grid(wd, ht, grid=args.grid),
+                # north_star's literal target: the same scene with SmoothTriangles (generated vertex normals; no bundled
+                # OBJ yields any, F2).  Next to other shapes the reference panics on some pixels (F5b): those are flagged
+                "teapot_smooth": lambda wd, ht: scenes.teapot_scene(wd, ht, obj_text=scenes.smooth_teapot_obj())}
 
     def make_job(w, cam, depth, width, height):
         """The per-frame step of one workload on this rank: scene resident, buffers allocated, nothing timed yet."""

@@ -250,6 +250,29 @@ int rt_device_count(void);
  * (src/world.rs:15-18) and of the global registries (src/lib.rs:46-54) — all resolved by the flattener. */
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 
+/* Behaviour switches of a scene, fixed at creation (no counterpart in the reference: none of them can change a result,
+ * every one has an on/off parity test).  In every field -1 means "library default"; the RT_AMD_* environment variable
+ * named with a field is read only when the field is -1 and exists for A/B measurements of an unmodified host. */
+typedef struct rt_scene_opts {
+    int32_t struct_size;        /* sizeof(rt_scene_opts): lets the library accept an older, shorter struct            */
+    int32_t cull_ranges;        /* world-space cull ranges over the top-level objects: -1/1 the library's rule (worlds
+                                   with >= 6 bounded top-level objects), 0 never                    [RT_AMD_CULL]      */
+    int32_t passive_triangles;  /* n1/n2 walk keeps only the last mesh triangle below the hit when that is provably
+                                   enough: -1/1 yes, 0 lists every triangle                  [RT_AMD_PASSIVE_TRIS]     */
+    int32_t frame_graph;        /* replay a frame's launches as one HIP graph: -1/1 yes, 0 plain enqueue [RT_AMD_GRAPH] */
+    int32_t device_bvh;         /* build the BVH of large meshes (>= 1024 distinct triangles) on the GPU — Morton order,
+                                   radix tree, boxes, leaves, BVH4 collapse — instead of the host's binned-SAH build:
+                                   -1/0 no (the SAH tree traces faster), 1 yes              [RT_AMD_DEVICE_BVH]        */
+    int32_t gather;             /* rt_render_multi: -1 RCCL when there is more than one device and it loads, else peer
+                                   copies; 1 RCCL even for one device; 2 peer copies always        [RT_AMD_GATHER]     */
+    int32_t verbose;            /* -1/0 quiet, 1 one line of scene statistics on stderr          [RT_AMD_VERBOSE]      */
+} rt_scene_opts;
+
+/* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is
+ * rt_scene_create; opts NULL = all defaults. */
+int rt_scene_create_opts(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, const rt_scene_opts* opts,
+                         rt_scene** out);
+
 /* Free everything rt_scene_create and later renders allocated for this scene. */
 void rt_scene_destroy(rt_scene* scene);
 

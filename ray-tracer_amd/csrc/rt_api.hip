@@ -906,13 +906,51 @@ int rt_device_count(void) {
     return n;
 }
 
+namespace {
+// rt_scene_opts with every -1 resolved: the field, else its RT_AMD_* variable, else the default
+struct Knobs {
+    bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
+    int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
+};
+void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
+    rt_scene_opts v;
+    std::memset(&v, 0xff, sizeof v);  // all -1
+    if (o) std::memcpy(&v, o, std::min(sizeof v, size_t(o->struct_size > 0 ? o->struct_size : 0)));
+    auto pick = [](int32_t field, const char* env, bool dflt) {
+        if (field >= 0) return field != 0;
+        if (const char* e = std::getenv(env)) return std::atoi(e) != 0;
+        return dflt;
+    };
+    k.cull = pick(v.cull_ranges, "RT_AMD_CULL", true);
+    k.passive = pick(v.passive_triangles, "RT_AMD_PASSIVE_TRIS", true);
+    k.graph = pick(v.frame_graph, "RT_AMD_GRAPH", true);
+    k.device_bvh = pick(v.device_bvh, "RT_AMD_DEVICE_BVH", false);
+    k.verbose = pick(v.verbose, "RT_AMD_VERBOSE", false);
+    k.gather = v.gather == 1 || v.gather == 2 ? v.gather : -1;
+    if (v.gather < 0)
+        if (const char* e = std::getenv("RT_AMD_GATHER")) k.gather = std::strcmp(e, "rccl") == 0 ? 1 : std::strcmp(e, "peer") == 0 ? 2 : -1;
+}
+int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, rt_scene** out);
+}  // namespace
+
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     if (!desc || !out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    Knobs knobs;
+    resolve_knobs(nullptr, knobs);
+    return scene_create_one(desc, device, knobs, out);
+}
+
+namespace {
+int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, rt_scene** out) {
     *out = nullptr;
     Program prog;
     std::string err;
     const int ndev0 = rt_device_count();
-    int rc = compile_program(*desc, prog, err, device >= 0 && device < ndev0 ? device : -1);
+    ProgramOpts popts;
+    popts.build_device = device >= 0 && device < ndev0 ? device : -1;
+    popts.device_bvh = knobs.device_bvh;
+    popts.cull_ranges = knobs.cull;
+    int rc = compile_program(*desc, prog, err, popts);
     if (rc != RT_OK) { rt_set_error("%s", err.c_str()); return rc; }
     if (prog.max_chain > MAX_CHAIN) { rt_set_error("transform chain deeper than %d levels", MAX_CHAIN); return RT_ERR_UNSUPPORTED; }
     int ndev = rt_device_count();
@@ -1034,10 +1072,9 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
             }
             m += cnt + 1;
         }
-        const char* e = std::getenv("RT_AMD_PASSIVE_TRIS");  // 0: never (A/B tests of the shortcut)
-        s->ds.passive_mesh_tris = unique && !(e && e[0] == '0') ? 1 : 0;
+        s->ds.passive_mesh_tris = unique && knobs.passive ? 1 : 0;
     }
-    if (std::getenv("RT_AMD_VERBOSE"))
+    if (knobs.verbose)
         std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items, %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
                      d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),
                      (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0));
@@ -1056,10 +1093,11 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         return fail(RT_ERR_HIP);
     }
     if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
-    if (const char* e = std::getenv("RT_AMD_GRAPH")) s->use_graph = std::atoi(e) != 0;
+    s->use_graph = knobs.graph;
     *out = s;
     return RT_OK;
 }
+}  // namespace
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
@@ -1210,8 +1248,16 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
 }
 
 int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, rt_scene** out) {
+    return rt_scene_create_opts(desc, n_gpus, devices, nullptr, out);
+}
+
+int rt_scene_create_opts(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, const rt_scene_opts* opts, rt_scene** out) {
     if (!desc || !out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
     *out = nullptr;
+    if (opts && opts->struct_size < int32_t(2 * sizeof(int32_t))) { rt_set_error("rt_scene_opts.struct_size is not set"); return RT_ERR_BAD_ARG; }
+    Knobs knobs;
+    resolve_knobs(opts, knobs);
+
     if (n_gpus < 1 || n_gpus > 64) { rt_set_error("n_gpus must be 1..64 (got %d)", n_gpus); return RT_ERR_BAD_ARG; }
     const int ndev = rt_device_count();
     if (ndev <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
@@ -1230,8 +1276,8 @@ int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32
     // every device compiles and uploads its own copy of the tables, in parallel (scene tables are small next to HBM:
     // the teapot is ~1.3 MB, a 1 M-triangle grid ~0.3 GB)
     MultiState* m = ms.get();
-    int rc = on_all_replicas(m, [m, desc](int r) -> int {
-        int rc2 = rt_scene_create(desc, m->devices[size_t(r)], &m->replicas[size_t(r)]);
+    int rc = on_all_replicas(m, [m, desc, &knobs](int r) -> int {
+        int rc2 = scene_create_one(desc, m->devices[size_t(r)], knobs, &m->replicas[size_t(r)]);
         if (rc2 != RT_OK) return rc2;
         HIP_TRY(hipEventCreateWithFlags(&m->sent[size_t(r)], hipEventDisableTiming));
         return RT_OK;
@@ -1248,11 +1294,10 @@ int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32
         return rc;
     }
     // ---- how the shards will travel
-    const char* want = std::getenv("RT_AMD_GATHER");  // "rccl": also for one device; "peer": never RCCL
-    const bool force_rccl = want && std::strcmp(want, "rccl") == 0, no_rccl = want && std::strcmp(want, "peer") == 0;
+    const bool force_rccl = knobs.gather == 1, no_rccl = knobs.gather == 2;
     if (n_gpus > 1 || force_rccl) {
         m->gather_kind = 2;
-        if (no_rccl) m->gather_note = "RT_AMD_GATHER=peer";
+        if (no_rccl) m->gather_note = "peer copies asked for (rt_scene_opts.gather / RT_AMD_GATHER)";
         else if (!distinct) m->gather_note = "the device list names a device twice (RCCL wants one rank per GPU)";
         else if (!rccl_api().ok()) m->gather_note = rccl_api().why;
         else {
@@ -1263,7 +1308,7 @@ int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32
         }
         if (m->gather_kind == 2) m->gather_note = "hipMemcpyPeerAsync: " + m->gather_note;
     }
-    if (std::getenv("RT_AMD_VERBOSE")) std::fprintf(stderr, "rt_scene_create_multi: %d replicas, gather: %s\n", n_gpus, m->gather_kind ? m->gather_note.c_str() : "none");
+    if (knobs.verbose) std::fprintf(stderr, "rt_scene_create_multi: %d replicas, gather: %s\n", n_gpus, m->gather_kind ? m->gather_note.c_str() : "none");
     (void)hipSetDevice(m->devices[0]);
     rt_scene* root = m->replicas[0];
     root->multi = ms.release();

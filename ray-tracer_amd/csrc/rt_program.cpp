@@ -23,7 +23,7 @@ struct Compiler {
     std::map<std::vector<int32_t>, int32_t> chain_index;
     std::map<std::pair<int32_t, int32_t>, int32_t> nchain_index;
 
-    int build_device = -1;  // >= 0 and RT_AMD_DEVICE_BVH=1: tree topology of large meshes from the GPU (rt_lbvh.hip)
+    ProgramOpts opts;       // build_device >= 0 and device_bvh: large meshes are built on the GPU (rt_lbvh.hip)
 
     Compiler(const rt_scene_desc& desc, Program& prog) : d(desc), p(prog) {}
 
@@ -341,8 +341,7 @@ struct Compiler {
         Box rb;
         int32_t root = 0;
         bool from_gpu = false;
-        const char* env = std::getenv("RT_AMD_DEVICE_BVH");
-        if (build_device >= 0 && env && env[0] == '1' && refs.size() >= size_t(LBVH_MIN_TRIANGLES)) {
+        if (opts.build_device >= 0 && opts.device_bvh && refs.size() >= size_t(LBVH_MIN_TRIANGLES)) {
             Box all;
             all.reset();
             std::vector<double> cen(refs.size() * 3);
@@ -352,7 +351,7 @@ struct Compiler {
             }
             Lbvh t;
             std::vector<int32_t> order;
-            if (lbvh_topology(build_device, refs.size(), cen.data(), all.lo, all.hi, order, t.left, t.right, t.first, t.last)) {
+            if (lbvh_topology(opts.build_device, refs.size(), cen.data(), all.lo, all.hi, order, t.left, t.right, t.first, t.last)) {
                 std::vector<TriRef> sorted(refs.size());
                 std::vector<char> seen(refs.size(), 0);
                 bool ok = true;
@@ -553,8 +552,7 @@ struct Compiler {
     static constexpr size_t CULL_MIN_OBJECTS = 6;
     void emit_culled(std::vector<std::pair<int32_t, WBox>>& roots, size_t lo, size_t hi) {
         if (hi - lo == 0) return;
-        const char* env = std::getenv("RT_AMD_CULL");  // 0: never (A/B tests of the acceleration)
-        if (roots.size() < CULL_MIN_OBJECTS || (env && env[0] == '0')) {
+        if (roots.size() < CULL_MIN_OBJECTS || !opts.cull_ranges) {
             for (size_t i = lo; i < hi; ++i) emit(roots[i].first, {});
             return;
         }
@@ -798,11 +796,11 @@ int validate(const rt_scene_desc& d, std::string& err) {
 
 }  // namespace
 
-int compile_program(const rt_scene_desc& d, Program& out, std::string& err, int build_device) {
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts) {
     int rc = validate(d, err);
     if (rc != RT_OK) return rc;
     Compiler c(d, out);
-    c.build_device = build_device;
+    c.opts = opts;
     // chain 0 = the empty chain
     c.chain_offset({});
     out.node_nchain.assign(size_t(d.n_nodes), -1);

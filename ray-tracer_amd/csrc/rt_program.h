@@ -90,10 +90,14 @@ struct Program {
 
 // Validates the descriptor (pointers, index ranges, affine inverses, CSG operand ids) and compiles it.
 // Returns RT_OK or an RT_ERR_* code with `err` set.
-// `build_device` >= 0: meshes of at least LBVH_MIN_TRIANGLES triangles take their tree topology from the GPU build
-// (rt_lbvh.hip) on that device when RT_AMD_DEVICE_BVH=1; everything else, and any mesh the GPU build fails on, uses
-// the host's binned-SAH build.
-int compile_program(const rt_scene_desc& d, Program& out, std::string& err, int build_device = -1);
+// `opts.build_device` >= 0 and `opts.device_bvh`: meshes of at least LBVH_MIN_TRIANGLES distinct triangles are built on
+// that GPU (rt_lbvh.hip); everything else, and any mesh the GPU build declines, uses the host's binned-SAH build.
+struct ProgramOpts {
+    int build_device = -1;
+    bool device_bvh = false;
+    bool cull_ranges = true;
+};
+int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts = ProgramOpts());
 
 // rt_lbvh.hip: Morton sort + binary radix tree of n >= 2 centroids on the GPU.  order[p] = index of the triangle at
 // sorted position p; internal node i covers positions first[i]..last[i] and has children left[i], right[i] (>= 0:

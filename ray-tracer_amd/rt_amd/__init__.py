@@ -160,7 +160,7 @@ class CMaterial(C.Structure):  # rth_material
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
                "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
-               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_render_multi",
+               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
@@ -200,6 +200,25 @@ lib.rt_canvas_to_ppm_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_
                                          C.c_void_p, C.c_void_p]
 lib.rt_canvas_to_ppm_noalloc.restype = C.c_int64
 lib.rt_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.c_int32, c_ip, C.POINTER(C.c_void_p)]
+
+
+class SceneOpts(C.Structure):
+    """rt_scene_opts (include/rt_abi.h): -1 = library default in every field."""
+    _fields_ = [("struct_size", C.c_int32), ("cull_ranges", C.c_int32), ("passive_triangles", C.c_int32), ("frame_graph", C.c_int32),
+                ("device_bvh", C.c_int32), ("gather", C.c_int32), ("verbose", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        for name, _ in self._fields_:
+            setattr(self, name, -1)
+        self.struct_size = C.sizeof(SceneOpts)
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("rt_scene_opts has no field " + k)
+            setattr(self, k, v)
+
+
+lib.rt_scene_create_opts.argtypes = [C.POINTER(SceneDesc), C.c_int32, c_ip, C.POINTER(SceneOpts), C.POINTER(C.c_void_p)]
 lib.rt_render_multi.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp, c_bp, C.POINTER(Stats)]
 lib.rt_scene_gpu_count.argtypes = [C.c_void_p]
 lib.rt_scene_gpu_count.restype = C.c_int32
@@ -725,11 +744,15 @@ class MultiScene:
     """A scene replicated on several GPUs of one node (rt_scene_create_multi); render() is Camera::render with the image
     tile-sharded over them and gathered to the first device (rt_render_multi)."""
 
-    def __init__(self, world, devices):
+    def __init__(self, world, devices, **scene_opts):
         devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
         self.h = C.c_void_p()
         self.n = len(devs)
-        _chk(lib.rt_scene_create_multi(world.flatten(), len(devs), devs.ctypes.data_as(c_ip), C.byref(self.h)))
+        if scene_opts:  # explicit switches (rt_scene_opts) instead of the defaults
+            so = SceneOpts(**scene_opts)
+            _chk(lib.rt_scene_create_opts(world.flatten(), len(devs), devs.ctypes.data_as(c_ip), C.byref(so), C.byref(self.h)))
+        else:
+            _chk(lib.rt_scene_create_multi(world.flatten(), len(devs), devs.ctypes.data_as(c_ip), C.byref(self.h)))
 
     def close(self):
         if self.h:

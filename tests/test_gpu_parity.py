@@ -880,3 +880,42 @@ def test_render_multi_rccl_gather_on_one_device(monkeypatch):
     assert np.array_equal(img.rgb, ref.rgb) and np.array_equal(img.hit_id, ref.hit_id)
     assert np.array_equal(img.q, ref.quantised().astype(np.uint8))
     ms.close()
+
+
+@pytest.mark.gpu
+def test_scene_opts_fields_switch_what_the_environment_variables_switch():
+    """rt_scene_opts (rt_abi.h): every behaviour switch as a field of the ABI.  None of them may change a result: C4 (CSG,
+    cull ranges, glass) and a mesh scene rendered with each switch flipped are bit-identical to the default scene, and the
+    device-BVH switch really builds on the GPU."""
+    for build, size, depth in ((scenes.mixed_scene, (160, 90), 5), (scenes.teapot_scene, (128, 72), 4)):
+        w, cam = build(*size)
+        ref = cam.render(w, depth=depth)
+        for kw in ({"cull_ranges": 0}, {"passive_triangles": 0}, {"frame_graph": 0}, {"device_bvh": 1}, {"gather": 1},
+                   {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0}):
+            ms = rt.MultiScene(w, [0], **kw)
+            try:
+                img = ms.render(cam, depth=depth)  # rt_render_multi (with rt_stats: plain launches)
+                assert np.array_equal(img.hit_id, ref.hit_id) and np.array_equal(img.rgb, ref.rgb) and np.array_equal(img.flags, ref.flags), kw
+                cd = cam.desc()
+                opts = rt.RenderOpts(max_depth=depth, rank=0, n_ranks=1, want_counters=0, stream=None)
+                for _ in range(2):  # rt_render without rt_stats: the second frame replays the graph where there is one
+                    rgb, ids = np.zeros_like(ref.rgb), np.zeros_like(ref.hit_id)
+                    rc = rt.lib.rt_render(ms.h, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), ids.ctypes.data_as(rt.c_ip), None, None)
+                    assert rc == 0, rt.last_error()
+                    assert np.array_equal(ids, ref.hit_id) and np.array_equal(rgb, ref.rgb), kw
+                if kw.get("device_bvh") == 1 and build is scenes.teapot_scene:
+                    assert rt.lib.rt_scene_meshes_built_on_gpu(ms.h) == 1
+                if kw.get("gather") == 1:
+                    assert ms.gather_kind in (1, 2)
+                else:
+                    assert ms.gather_kind == 0
+            finally:
+                ms.close()
+    with pytest.raises(rt.RtError):  # struct_size must be set
+        bad = rt.SceneOpts()
+        bad.struct_size = 0
+        h = C.c_void_p()
+        w, cam = scenes.book_world(16, 16)
+        rc = rt.lib.rt_scene_create_opts(w.flatten(), 1, None, C.byref(bad), C.byref(h))
+        if rc < 0:
+            raise rt.RtError(int(rc), rt.last_error())
