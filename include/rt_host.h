@@ -74,6 +74,10 @@ int rth_triangle_data(int shape, double* out27);
 /* parse_obj_file + obj_to_group.  counts_out (nullable) = {lines_ignored, vertices.len(), normals.len(),
  * groups.len(), total triangles}.  Returns the handle of the main group. */
 int rth_obj_to_group(const char* text, int64_t len, int32_t* counts_out);
+/* The same group with its children kept as packed triangle records until a caller asks for them as shapes (SURVEY.md
+ * section 8(f) row 3: src/obj_file.rs:29-172 without a Shape, a clone and a registry update per triangle,
+ * src/group.rs:45-50,71-84).  Same object ids, same registry entries, same flattened tables. */
+int rth_obj_file_to_group(const char* text, int64_t len, int32_t* counts_out);
 
 /* ---- src/world.rs ---- */
 /* Builds a World from CLONES of the given shapes (world.objects order) and lights (world.lights order). */

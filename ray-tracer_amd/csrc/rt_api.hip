@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -950,6 +951,8 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     popts.build_device = device >= 0 && device < ndev0 ? device : -1;
     popts.device_bvh = knobs.device_bvh;
     popts.cull_ranges = knobs.cull;
+    popts.verbose = knobs.verbose;
+    const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);
     if (rc != RT_OK) { rt_set_error("%s", err.c_str()); return rc; }
     if (prog.max_chain > MAX_CHAIN) { rt_set_error("transform chain deeper than %d levels", MAX_CHAIN); return RT_ERR_UNSUPPORTED; }
@@ -1039,7 +1042,9 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         // stack rows beyond LDS_STACK, one column per lane that can be resident (2048 lanes per CU at most)
         s->ds.spill_lanes = (long long)s->n_cus * 2048;
         void* sp = nullptr;
-        if (hipMalloc(&sp, size_t(BVH_STACK - LDS_STACK) * size_t(s->ds.spill_lanes) * sizeof(int32_t)) != hipSuccess) {
+        // as many rows as this scene's deepest tree can ask for (3 pending siblings per BVH4 level; host-built trees: <= 31)
+        const int spill_rows = std::max(1, 3 * int(prog.bvh_max_depth) + 1 - LDS_STACK);
+        if (hipMalloc(&sp, size_t(spill_rows) * size_t(s->ds.spill_lanes) * sizeof(int32_t)) != hipSuccess) {
             rt_set_error("could not allocate the traversal stack spill area");
             return fail(RT_ERR_HIP);
         }
@@ -1074,6 +1079,8 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         }
         s->ds.passive_mesh_tris = unique && knobs.passive ? 1 : 0;
     }
+    if (knobs.verbose)
+        std::fprintf(stderr, "rt_scene_create: %.3f s so far (compile + uploads)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create0).count());
     if (knobs.verbose)
         std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items, %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
                      d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),

@@ -83,7 +83,7 @@ struct DScene {
     char* arena;
     long long arena_lane_bytes;       // csg_cap * 28 + list_cap * 16
     int32_t arena_csg_cap, arena_list_cap;
-    int32_t* spill;                   // [BVH_STACK - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
+    int32_t* spill;                   // [3 * deepest tree + 1 - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
     long long spill_lanes;
 };
 

@@ -3,6 +3,7 @@
 #include "rt_program.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,8 @@ struct Compiler {
     std::map<std::pair<int32_t, int32_t>, int32_t> nchain_index;
 
     ProgramOpts opts;       // build_device >= 0 and device_bvh: large meshes are built on the GPU (rt_lbvh.hip)
+    double t_dedup = 0., t_refs = 0., t_tree = 0.;  // seconds spent in build_mesh's phases (opts.verbose)
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     Compiler(const rt_scene_desc& desc, Program& prog) : d(desc), p(prog) {}
 
@@ -197,33 +200,6 @@ struct Compiler {
         return me;
     }
 
-    // ---- tree topology from the GPU build ----------------------------------------------------------------
-    struct Lbvh {
-        std::vector<int32_t> left, right, first, last;
-    };
-    // Node i of the radix tree over `sorted` -> child reference + padded box, as build() returns them.  A node of at
-    // most BVH_LEAF_MAX triangles becomes a leaf; a subtree that would not fit the depth bound is rebuilt by build().
-    int32_t from_lbvh(const Lbvh& t, std::vector<TriRef>& sorted, int32_t ref, Box& box, int depth) {
-        size_t lo, hi;  // positions [lo, hi)
-        if (ref < 0) { lo = size_t(~ref); hi = lo + 1; }
-        else { lo = size_t(t.first[size_t(ref)]); hi = size_t(t.last[size_t(ref)]) + 1; }
-        const size_t n = hi - lo;
-        int lg = 0;
-        while ((size_t(1) << lg) < n) ++lg;
-        if (ref < 0 || n <= size_t(BVH_LEAF_MAX) || depth + lg + 3 >= BVH2_MAX_DEPTH) return build(sorted, lo, hi, box, depth);
-        int32_t me = int32_t(n2.size());
-        n2.emplace_back();
-        Box b0, b1;
-        int32_t c0 = from_lbvh(t, sorted, t.left[size_t(ref)], b0, depth + 1);
-        int32_t c1 = from_lbvh(t, sorted, t.right[size_t(ref)], b1, depth + 1);
-        Node2& nd = n2[size_t(me)];
-        nd.box[0] = b0; nd.box[1] = b1;
-        nd.child[0] = c0; nd.child[1] = c1;
-        box = b0;
-        box.add(b1.lo, b1.hi);
-        return me;
-    }
-
     static float round_down(double x) {
         float f = float(x);
         if (double(f) > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
@@ -283,6 +259,7 @@ struct Compiler {
         // hundred on polygon faces, F3: teapot-low.obj is 15,136 triangles but 151 distinct ones).
         std::vector<int32_t> tri_nodes;
         std::vector<int32_t> dups_of;
+        const double t0 = now();
         {
             struct Key {
                 double v[9];
@@ -319,6 +296,8 @@ struct Compiler {
                 p.mesh_dups.insert(p.mesh_dups.end(), extra[i].begin(), extra[i].end());
             }
         }
+        const double t1 = now();
+        t_dedup += t1 - t0;
         std::vector<TriRef> refs(tri_nodes.size());
         double maxabs = 0.;
         for (size_t i = 0; i < tri_nodes.size(); ++i) {
@@ -337,38 +316,51 @@ struct Compiler {
         // Conservative padding: the reference accepts u,v in [0,1] as COMPUTED (relative error ~1e-16) and our
         // p2/p3 are re-derived from edges; 1e-7 of the mesh scale is nine orders of magnitude above both.
         pad = 1e-7 * maxabs + 1e-300;
+        const double t2 = now();
+        t_refs += t2 - t1;
+        struct Stop { double& acc; double from; ~Stop() { acc += now() - from; } } stop{t_tree, t2};
         n2.clear();
         Box rb;
         int32_t root = 0;
-        bool from_gpu = false;
         if (opts.build_device >= 0 && opts.device_bvh && refs.size() >= size_t(LBVH_MIN_TRIANGLES)) {
-            Box all;
-            all.reset();
-            std::vector<double> cen(refs.size() * 3);
-            for (size_t i = 0; i < refs.size(); ++i) {
-                all.add(refs[i].c, refs[i].c);
-                for (int k = 0; k < 3; ++k) cen[3 * i + size_t(k)] = refs[i].c[k];
-            }
-            Lbvh t;
-            std::vector<int32_t> order;
-            if (lbvh_topology(opts.build_device, refs.size(), cen.data(), all.lo, all.hi, order, t.left, t.right, t.first, t.last)) {
-                std::vector<TriRef> sorted(refs.size());
+            // the whole tree on the GPU (rt_lbvh.hip): Morton order, radix tree, boxes, leaves, BVH4 collapse
+            std::vector<double> tlo(refs.size() * 3), thi(refs.size() * 3);
+            for (size_t i = 0; i < refs.size(); ++i)
+                for (int k = 0; k < 3; ++k) { tlo[3 * i + size_t(k)] = refs[i].lo[k]; thi[3 * i + size_t(k)] = refs[i].hi[k]; }
+            std::vector<int32_t> order, level_start;
+            std::vector<BvhNode> nodes;
+            double root_box[6];
+            const int32_t tri_base = int32_t(p.mesh_tris.size());
+            if (lbvh_build(opts.build_device, refs.size(), tlo.data(), thi.data(), pad, tri_base, (BVH_STACK - 1) / 3, order, nodes, level_start,
+                           root_box)) {
+                bool ok = order.size() == refs.size() && !nodes.empty() && level_start.size() >= 2;
                 std::vector<char> seen(refs.size(), 0);
-                bool ok = true;
                 for (size_t q = 0; q < order.size() && ok; ++q) {
                     const size_t i = size_t(order[q]);
                     ok = order[q] >= 0 && i < refs.size() && !seen[i];
-                    if (ok) { seen[i] = 1; sorted[q] = refs[i]; }
+                    if (ok) seen[i] = 1;
                 }
                 if (ok) {
-                    root = from_lbvh(t, sorted, 0, rb, 0);
-                    refs.swap(sorted);
-                    from_gpu = true;
+                    std::vector<TriRef> sorted(refs.size());
+                    for (size_t q = 0; q < order.size(); ++q) sorted[q] = refs[size_t(order[q])];
+                    emit_leaf(sorted, 0, sorted.size());  // the MeshTri records in leaf order; the device encoded the leaf links
+                    const int32_t base = int32_t(n4.size());
+                    for (size_t lv = 0; lv + 1 < level_start.size(); ++lv)
+                        for (int32_t i = level_start[lv]; i < level_start[lv + 1]; ++i) {
+                            BvhNode nd = nodes[size_t(i)];
+                            for (int c = 0; c < 4; ++c)
+                                if (nd.child[c] >= 0) nd.child[c] += base;
+                            n4.push_back(nd);
+                            n4_depth.push_back(int(lv));
+                        }
+                    p.bvh_max_depth = std::max(p.bvh_max_depth, int32_t(level_start.size()) - 1);
+                    for (int k = 0; k < 3; ++k) { last_mesh_box.lo[k] = root_box[k]; last_mesh_box.hi[k] = root_box[3 + k]; }
                     ++p.meshes_built_on_gpu;
+                    return base;
                 }
             }
         }
-        if (!from_gpu) root = build(refs, 0, refs.size(), rb, 0);
+        root = build(refs, 0, refs.size(), rb, 0);
         last_mesh_box = rb;
         if (root < 0) {  // the whole mesh is one leaf: wrap it in a node
             Node2 nd;
@@ -797,8 +789,10 @@ int validate(const rt_scene_desc& d, std::string& err) {
 }  // namespace
 
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts) {
+    const double t_begin = Compiler::now();
     int rc = validate(d, err);
     if (rc != RT_OK) return rc;
+    const double t_validated = Compiler::now();
     Compiler c(d, out);
     c.opts = opts;
     // chain 0 = the empty chain
@@ -837,7 +831,13 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
             if (!d.node_casts_shadow[n]) out.all_cast_shadow = false;
         }
     }
+    const double t_emitted = Compiler::now();
     c.finish_bvh();
+    if (opts.verbose)
+        std::fprintf(stderr, "compile_program: validate %.3f s, program + meshes %.3f s (of which de-duplication %.3f, triangle bounds %.3f, trees %.3f), "
+                             "depth ordering %.3f s; %d meshes built on the GPU, deepest tree %d levels\n",
+                     t_validated - t_begin, t_emitted - t_validated, c.t_dedup, c.t_refs, c.t_tree, Compiler::now() - t_emitted,
+                     out.meshes_built_on_gpu, out.bvh_max_depth);
     if (3 * out.bvh_max_depth + 1 > BVH_STACK) {
         err = "BVH deeper than the device traversal stack";
         return RT_ERR_UNSUPPORTED;

@@ -96,20 +96,25 @@ struct ProgramOpts {
     int build_device = -1;
     bool device_bvh = false;
     bool cull_ranges = true;
+    bool verbose = false;   // phase times of the compilation on stderr
 };
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts = ProgramOpts());
 
-// rt_lbvh.hip: Morton sort + binary radix tree of n >= 2 centroids on the GPU.  order[p] = index of the triangle at
-// sorted position p; internal node i covers positions first[i]..last[i] and has children left[i], right[i] (>= 0:
-// internal node, < 0: ~position).  Node 0 is the root.  false: not built (the caller uses the host build).
-bool lbvh_topology(int device, size_t n, const double* centroids, const double* box_lo, const double* box_hi,
-                   std::vector<int32_t>& order, std::vector<int32_t>& left, std::vector<int32_t>& right,
-                   std::vector<int32_t>& first, std::vector<int32_t>& last);
+// rt_lbvh.hip: the whole BVH of one mesh on the GPU.  tri_lo / tri_hi [n][3]: unpadded bounds of the distinct
+// triangles; tri_base: index the mesh's first MeshTri will have (leaves are encoded with it).  On success: order[p] =
+// triangle at leaf-order position p (the caller emits its MeshTri records in that order), `nodes` = the BVH4 nodes in
+// breadth-first order with mesh-local child indices (node 0 = root), level_start[k] .. level_start[k + 1] = the nodes of
+// depth k, root_box = padded f64 bounds of the mesh.  false: declined (too small, too deep for `max_levels`, not
+// finite, out of memory, HIP error) — the caller builds on the host.
+struct BvhNode;
+bool lbvh_build(int device, size_t n, const double* tri_lo, const double* tri_hi, double pad, int32_t tri_base, int max_levels,
+                std::vector<int32_t>& order, std::vector<BvhNode>& nodes, std::vector<int32_t>& level_start, double root_box[6]);
 
 constexpr int LBVH_MIN_TRIANGLES = 1024; // smaller meshes are always built on the host
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
 constexpr int BVH_LEAF_MAX = 4;        // triangles per leaf (measured: 1 -> 2.74 ms, 2 -> 2.21 ms, 4 -> 2.12 ms per frame); fetched two at a time
-constexpr int BVH_STACK = 32;          // device traversal stack entries per ray: 3 pending siblings per BVH4 level
+constexpr int BVH_STACK = 64;          // most device traversal stack entries per ray a scene may need: 3 pending siblings per BVH4 level
+                                       // (the spill area is sized by what the scene's trees do need: host-built trees stay within 31)
 constexpr int BVH2_MAX_DEPTH = 20;     // binary build depth bound; the collapse halves it: 3 * 10 <= BVH_STACK
 
 }  // namespace rt

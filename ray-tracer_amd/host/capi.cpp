@@ -222,6 +222,10 @@ int rth_obj_to_group(const char* text, int64_t len, int32_t* counts_out) {
     });
 }
 
+int rth_obj_file_to_group(const char* text, int64_t len, int32_t* counts_out) {
+    return guarded([&] { return put_shape(obj_file_to_group(std::string(text, size_t(len)), counts_out)); });
+}
+
 int rth_world_create(const int* shape_handles, int n_shapes, const double* lp, const double* li, int n_lights) {
     return guarded([&] {
         auto slot = std::make_unique<WorldSlot>();

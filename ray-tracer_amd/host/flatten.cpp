@@ -10,6 +10,8 @@
 //   * Group gate boxes come from Group::bounds_of on the snapshot (src/group.rs:86-95), +-inf included;
 //   * Shape::eq (per-struct PartialEq) is folded into an equality class per node.
 #include <cstring>
+#include <deque>
+#include <limits>
 #include <map>
 #include <unordered_map>
 
@@ -77,8 +79,17 @@ struct Flattener {
     std::unordered_map<int, int32_t> ancestor_of_id;        // registry id -> ancestor index
     std::unordered_map<int, int32_t> xform_of_matrix_id;    // matrix id -> xform index
     std::unordered_map<int, std::vector<int32_t>> nodes_of_object;  // object id -> leaf nodes seen so far
-    std::vector<const Shape*> node_shape;
+    std::vector<const Shape*> node_shape;  // null for the nodes of a packed mesh (see visit_packed)
     std::vector<std::pair<Material, int32_t>> materials;  // content-deduplicated
+    // Packed meshes flattened so far: their (contiguous) id range and where their nodes are, so that a later leaf with
+    // one of those ids finds the earlier node Shape::eq has to be asked about.
+    struct PackedSeen {
+        const PackedMesh* mesh;
+        int32_t main_node;
+    };
+    std::vector<PackedSeen> packed_seen;
+    std::deque<Shape> unpacked_copies;  // packed groups that had to take the Shape-by-Shape path (kept alive for node_shape)
+    int min_leaf_id = std::numeric_limits<int>::max(), max_leaf_id = std::numeric_limits<int>::min();  // of unpacked leaves
 
     Flattener() {
         // xform 0 is always the exact identity
@@ -183,7 +194,127 @@ struct Flattener {
         v.push_back(t.z);
     }
 
+    static bool self_equal(const PackedTri& t) {  // Triangle / SmoothTriangle PartialEq of a value with itself (F14)
+        bool eq = t.p1 == t.p1 && t.p2 == t.p2 && t.p3 == t.p3 && t.e1 == t.e1 && t.e2 == t.e2 && t.normal == t.normal;
+        if (t.smooth) eq = eq && t.n1 == t.n1 && t.n2 == t.n2 && t.n3 == t.n3;
+        return eq;
+    }
+
+    // Nodes of earlier packed meshes that carry object id `id` (a mesh cloned into the world twice, or a leaf of an
+    // unpacked clone): the node and a Shape made from its record.
+    std::vector<std::pair<int32_t, Shape>> packed_nodes_with_id(int id) const {
+        std::vector<std::pair<int32_t, Shape>> out;
+        for (const PackedSeen& ps : packed_seen) {
+            if (id < ps.mesh->id_first || id > ps.mesh->id_last) continue;
+            int32_t node = ps.main_node + 1;
+            for (const PackedGroup& g : ps.mesh->groups) {
+                for (size_t k = 0; k < g.tris.size(); ++k)
+                    if (g.tris[k].id == id) out.emplace_back(node + 1 + int32_t(k), Shape::FromPackedTri(g.tris[k], g.id));
+                node += 1 + int32_t(g.tris.size());
+            }
+        }
+        return out;
+    }
+
+    // Group::bounds_of of the main group (src/group.rs:86-95): the union of its sub-groups' parent-space boxes
+    static Bound packed_main_bounds(const PackedMesh& m) {
+        const Bound tri_box = Bound::bounding_box_empty().transform(Matrix::identity(4));
+        Bound b = Bound::bounding_box_empty();
+        for (const PackedGroup& g : m.groups) {
+            Bound gb = Bound::bounding_box_empty();
+            for (size_t k = 0; k < g.tris.size() && k < 3; ++k) gb.add_box(tri_box);
+            b.add_box(gb.transform(Matrix::identity(4)));
+        }
+        return b;
+    }
+
+    // The children of a Group that obj_file_to_group built, straight from the packed records: the same nodes, in the
+    // same order, with the same values as visit() produces for the unpacked tree.
+    void visit_packed(const Shape& main, int32_t main_node) {
+        const PackedMesh& m = *main.packed();
+        // per-triangle constants of this mesh.  Every triangle and every sub-group has the identity transform (xform 0).
+        // Group::bounds_of of a sub-group (src/group.rs:86-95): the union of its triangles' parent-space boxes, which are
+        // all the same box — the empty box (src/triangle.rs:93-95) through the identity transform
+        const Bound tri_box = Bound::bounding_box_empty().transform(Matrix::identity(4));
+        packed_seen.push_back({&m, main_node});
+        for (const PackedGroup& g : m.groups) {
+            const int32_t gn = int32_t(f.node_kind.size());
+            Bound gb = Bound::bounding_box_empty();
+            for (size_t k = 0; k < g.tris.size() && k < 3; ++k) gb.add_box(tri_box);  // identical boxes: a fixed point after the first
+            f.node_kind.push_back(int32_t(ShapeKind::Group));
+            f.node_object_id.push_back(g.id);
+            f.node_parent.push_back(main_node);
+            f.node_subtree_end.push_back(gn + 1 + int32_t(g.tris.size()));
+            f.node_xform.push_back(0);
+            f.node_ancestor.push_back(-1);
+            f.node_material.push_back(-1);
+            f.node_casts_shadow.push_back(1);
+            f.node_eq_class.push_back(-1);
+            f.node_param.push_back(int32_t(f.group_box.size() / 6));
+            for (double v : {gb.minimum.x, gb.minimum.y, gb.minimum.z, gb.maximum.x, gb.maximum.y, gb.maximum.z}) f.group_box.push_back(v);
+            node_shape.push_back(nullptr);
+            if (g.tris.empty()) continue;
+            const int32_t anc = ancestor_for(g.id);
+            // Shape::get_material of a triangle: the material of its root ancestor in the registry (src/shape.rs:163-184)
+            const RegistryEntry* e = registry_find(g.id);
+            while (true) {
+                if (!e) throw Panic("called `Option::unwrap()` on a `None` value (parent id not in PARENT_REFERENCES)");
+                if (!e->parent) break;
+                e = registry_find(*e->parent);
+            }
+            const int32_t mat = material_for(e->material);
+            const size_t n0 = f.node_kind.size(), nt = g.tris.size();
+            f.node_kind.resize(n0 + nt);
+            f.node_object_id.resize(n0 + nt);
+            f.node_parent.resize(n0 + nt, gn);
+            f.node_subtree_end.resize(n0 + nt);
+            f.node_xform.resize(n0 + nt, 0);
+            f.node_ancestor.resize(n0 + nt, anc);
+            f.node_material.resize(n0 + nt, mat);
+            f.node_casts_shadow.resize(n0 + nt, 1);
+            f.node_eq_class.resize(n0 + nt);
+            f.node_param.resize(n0 + nt);
+            node_shape.resize(n0 + nt, nullptr);
+            const size_t t0 = f.tri_smooth.size();
+            f.tri_p1.resize(3 * (t0 + nt)); f.tri_e1.resize(3 * (t0 + nt)); f.tri_e2.resize(3 * (t0 + nt)); f.tri_normal.resize(3 * (t0 + nt));
+            f.tri_smooth.resize(t0 + nt);
+            for (size_t k = 0; k < nt; ++k) {
+                const PackedTri& t = g.tris[k];
+                const size_t n = n0 + k, ti = t0 + k;
+                f.node_kind[n] = int32_t(t.smooth ? ShapeKind::SmoothTriangle : ShapeKind::Triangle);
+                f.node_object_id[n] = t.id;
+                f.node_subtree_end[n] = int32_t(n) + 1;
+                f.node_param[n] = int32_t(ti);
+                f.node_eq_class[n] = self_equal(t) ? int32_t(n) : -1;
+                const Tuple* src[4] = {&t.p1, &t.e1, &t.e2, &t.normal};
+                double* dst[4] = {f.tri_p1.data(), f.tri_e1.data(), f.tri_e2.data(), f.tri_normal.data()};
+                for (int a = 0; a < 4; ++a) { dst[a][3 * ti] = src[a]->x; dst[a][3 * ti + 1] = src[a]->y; dst[a][3 * ti + 2] = src[a]->z; }
+                if (t.smooth) {
+                    f.tri_smooth[ti] = int32_t(f.smooth_n1.size() / 3);
+                    push3(f.smooth_n1, t.n1);
+                    push3(f.smooth_n2, t.n2);
+                    push3(f.smooth_n3, t.n3);
+                } else {
+                    f.tri_smooth[ti] = -1;
+                }
+            }
+        }
+    }
+
     void visit(const Shape& s, int32_t parent_node) {
+        if (s.kind() == ShapeKind::Group && s.packed()) {
+            // The packed path needs no Shape::eq look-ups only if none of the mesh's ids has been seen in this world yet
+            // (neither in an earlier packed mesh nor in an unpacked leaf); else a copy is unpacked and visited Shape by Shape
+            const PackedMesh& m = *s.packed();
+            bool clash = !(m.id_last < min_leaf_id || m.id_first > max_leaf_id);
+            for (const PackedSeen& ps : packed_seen) clash = clash || !(m.id_last < ps.mesh->id_first || m.id_first > ps.mesh->id_last);
+            if (clash) {
+                unpacked_copies.emplace_back(s);
+                unpacked_copies.back().unpack();
+                visit(unpacked_copies.back(), parent_node);
+                return;
+            }
+        }
         int32_t me = int32_t(f.node_kind.size());
         f.node_kind.push_back(int32_t(s.kind()));
         f.node_object_id.push_back(s.get_id());
@@ -199,11 +330,13 @@ struct Flattener {
 
         switch (s.kind()) {
             case ShapeKind::Group: {
-                Bound b = s.bounds_of();
+                Bound b = s.packed() ? packed_main_bounds(*s.packed()) : s.bounds_of();
                 f.node_param[size_t(me)] = int32_t(f.group_box.size() / 6);
                 for (double v : {b.minimum.x, b.minimum.y, b.minimum.z, b.maximum.x, b.maximum.y, b.maximum.z})
                     f.group_box.push_back(v);
-                for (const Shape& c : s.shapes) visit(c, me);
+                if (s.packed()) visit_packed(s, me);
+                else
+                    for (const Shape& c : s.shapes) visit(c, me);
                 break;
             }
             case ShapeKind::CSG: {
@@ -241,14 +374,24 @@ struct Flattener {
                     }
                 }
                 // Shape::eq folded into a class id (F14: a shape may be unequal to itself)
+                min_leaf_id = std::min(min_leaf_id, s.get_id());
+                max_leaf_id = std::max(max_leaf_id, s.get_id());
                 if (s == s) {
                     int32_t cls = me;
                     auto& seen = nodes_of_object[s.get_id()];
+                    bool found = false;
                     for (int32_t other : seen)
                         if (f.node_eq_class[size_t(other)] >= 0 && *node_shape[size_t(other)] == s) {
                             cls = f.node_eq_class[size_t(other)];
+                            found = true;
                             break;
                         }
+                    if (!found && !packed_seen.empty())
+                        for (const auto& cand : packed_nodes_with_id(s.get_id()))
+                            if (f.node_eq_class[size_t(cand.first)] >= 0 && cand.second == s) {
+                                cls = f.node_eq_class[size_t(cand.first)];
+                                break;
+                            }
                     f.node_eq_class[size_t(me)] = cls;
                     seen.push_back(me);
                 }

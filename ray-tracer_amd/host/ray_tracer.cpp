@@ -4,7 +4,9 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <charconv>
 #include <sstream>
+#include <string_view>
 #include <unordered_map>
 
 namespace ray_tracer {
@@ -230,6 +232,38 @@ Shape Shape::SmoothTriangle(const Tuple& p1, const Tuple& p2, const Tuple& p3, c
     return s;
 }
 Shape Shape::Group() { return Shape(ShapeKind::Group); }
+Shape Shape::FromPackedTri(const PackedTri& t, int parent_id) {
+    Shape s(t.smooth ? ShapeKind::SmoothTriangle : ShapeKind::Triangle, t.id);
+    s.point1 = t.p1; s.point2 = t.p2; s.point3 = t.p3;
+    s.edge_vector1 = t.e1; s.edge_vector2 = t.e2; s.normal_vector = t.normal;
+    if (t.smooth) { s.normal_vector1 = t.n1; s.normal_vector2 = t.n2; s.normal_vector3 = t.n3; }
+    s.parent = parent_id;
+    return s;
+}
+Shape Shape::FromPackedMesh(std::shared_ptr<const PackedMesh> mesh) {
+    Shape s(ShapeKind::Group);
+    // what the add_child calls of parse_obj_file / obj_to_group leave in PARENT_REFERENCES: every sub-group with the main
+    // group as its parent (src/group.rs:45-50, src/shape.rs:357-378), then the main group itself
+    for (const PackedGroup& g : mesh->groups)
+        parent_references().insert_or_assign(g.id, RegistryEntry{g.id, Matrix::identity(4), Material(), s.id_});
+    s.packed_ = std::move(mesh);
+    s.update_reference();
+    return s;
+}
+// The Shape tree obj_to_group would have built: sub-groups and triangles with the ids, parents and fields the packed
+// records carry (the registry entries of the sub-groups exist since the parse).
+void Shape::unpack() const {
+    if (!packed_) return;
+    std::shared_ptr<const PackedMesh> m = std::move(packed_);
+    packed_.reset();
+    for (const PackedGroup& g : m->groups) {
+        Shape sg(ShapeKind::Group, g.id);
+        sg.parent = id_;
+        sg.shapes.reserve(g.tris.size());
+        for (const PackedTri& t : g.tris) sg.shapes.push_back(FromPackedTri(t, g.id));
+        shapes.push_back(std::move(sg));
+    }
+}
 Shape Shape::CSG(const std::string& operation, Shape& left, Shape& right) {  // src/csg.rs:33-53
     Shape s(ShapeKind::CSG);
     left.set_parent(s.id_);
@@ -247,7 +281,7 @@ Shape::Shape(const Shape& o)
       point3(o.point3), edge_vector1(o.edge_vector1), edge_vector2(o.edge_vector2), normal_vector(o.normal_vector),
       normal_vector1(o.normal_vector1), normal_vector2(o.normal_vector2), normal_vector3(o.normal_vector3),
       shapes(o.shapes), operation(o.operation), left(o.left ? std::make_unique<Shape>(*o.left) : nullptr),
-      right(o.right ? std::make_unique<Shape>(*o.right) : nullptr), kind_(o.kind_), id_(o.id_) {}
+      right(o.right ? std::make_unique<Shape>(*o.right) : nullptr), kind_(o.kind_), id_(o.id_), packed_(o.packed_) {}
 Shape& Shape::operator=(const Shape& o) {
     if (this != &o) {
         Shape tmp(o);
@@ -313,10 +347,12 @@ void Shape::set_closed(bool v) {
 }
 const std::vector<Shape>& Shape::get_shapes() const {
     if (kind_ != ShapeKind::Group) throw Panic("Only groups can contain children.");
+    unpack();
     return shapes;
 }
 void Shape::add_child(Shape& child) {  // src/group.rs:45-50
     if (kind_ != ShapeKind::Group) throw Panic("Only groups can contain children.");
+    unpack();
     child.set_parent(id_);
     shapes.push_back(child);
     update_reference();
@@ -324,6 +360,7 @@ void Shape::add_child(Shape& child) {  // src/group.rs:45-50
 bool Shape::includes(const Shape& other) const {  // src/shape.rs:422-435
     switch (kind_) {
         case ShapeKind::Group:
+            unpack();
             for (const Shape& s : shapes)
                 if (s.includes(other)) return true;
             return false;
@@ -347,6 +384,7 @@ Bound Shape::bounds_of() const {
             return Bound::bounding_box_init(Tuple::point(-limit, minimum, -limit), Tuple::point(limit, maximum, limit));
         }
         case ShapeKind::Group: {  // src/group.rs:86-95
+            unpack();
             Bound b = Bound::bounding_box_empty();
             for (const Shape& s : shapes) b.add_box(s.parent_space_bounds_of());
             return b;
@@ -357,6 +395,7 @@ Bound Shape::bounds_of() const {
 }
 std::pair<std::vector<Shape>, std::vector<Shape>> Shape::partition_children() {  // src/group.rs:97-123
     if (kind_ != ShapeKind::Group) throw Panic("Only groups can partition children.");
+    unpack();
     auto [left_box, right_box] = bounds_of().split_bounds();
     std::vector<Shape> l, r, keep;
     for (Shape& s : shapes) {
@@ -376,6 +415,7 @@ void Shape::make_subgroup(std::vector<Shape> list) {  // src/group.rs:125-132
 }
 void Shape::divide(size_t threshold) {  // src/group.rs:134-149, src/shape.rs:470-475
     if (kind_ != ShapeKind::Group) return;
+    unpack();
     if (threshold <= shapes.size()) {
         auto [l, r] = partition_children();
         if (!l.empty()) make_subgroup(std::move(l));
@@ -439,28 +479,39 @@ Shape hexagon() {
 }
 
 // ---------------------------------------------------------------- obj_file.rs
-static std::vector<std::string> split_whitespace(const std::string& line) {
-    std::vector<std::string> out;
+// Tokens are views into the file text: no allocation per line or per token (a 1 M-triangle OBJ has 4 M lines).
+static void split_whitespace(std::string_view line, std::vector<std::string_view>& out) {
+    out.clear();
     size_t i = 0, n = line.size();
     while (i < n) {
         while (i < n && std::isspace(static_cast<unsigned char>(line[i]))) ++i;
         size_t j = i;
         while (j < n && !std::isspace(static_cast<unsigned char>(line[j]))) ++j;
-        if (j > i) out.emplace_back(line, i, j - i);
+        if (j > i) out.push_back(line.substr(i, j - i));
         i = j;
     }
-    return out;
 }
-static bool parse_f64(const std::string& s, double& out) {  // str::parse::<f64>
+static bool parse_f64(std::string_view s, double& out) {  // str::parse::<f64>
     if (s.empty()) return false;
     for (char c : s)
         if (c == 'x' || c == 'X' || c == 'p' || c == 'P' || c == '(' || std::isspace(static_cast<unsigned char>(c)))
             return false;
+    {   // fast lane: a plain decimal literal that std::from_chars takes whole (same correctly rounded value as strtod);
+        // anything it stops early on, or finds out of range, is decided by strtod below as before
+        double v;
+        const std::from_chars_result r = std::from_chars(s.data(), s.data() + s.size(), v);
+        if (r.ec == std::errc() && r.ptr == s.data() + s.size()) { out = v; return true; }
+    }
+    char small[64];
+    std::string big;
+    const char* z;
+    if (s.size() < sizeof small) { std::memcpy(small, s.data(), s.size()); small[s.size()] = 0; z = small; }
+    else { big.assign(s); z = big.c_str(); }
     char* end = nullptr;
-    out = std::strtod(s.c_str(), &end);
-    return end == s.c_str() + s.size();
+    out = std::strtod(z, &end);
+    return end == z + s.size();
 }
-static bool parse_usize(const std::string& s, size_t& out) {  // str::parse::<usize>
+static bool parse_usize(std::string_view s, size_t& out) {  // str::parse::<usize>
     size_t i = 0;
     if (!s.empty() && s[0] == '+') i = 1;
     if (i >= s.size()) return false;
@@ -474,90 +525,108 @@ static bool parse_usize(const std::string& s, size_t& out) {  // str::parse::<us
     out = static_cast<size_t>(v);
     return true;
 }
-static std::vector<Shape> fan_triangulation(const std::vector<Tuple>& v) {  // src/obj_file.rs:143-151 (F3: whole list)
-    std::vector<Shape> t;
-    for (size_t i = 2; i + 1 < v.size(); ++i) t.push_back(Shape::Triangle(v[1], v[i], v[i + 1]));
-    return t;
-}
-static std::vector<Shape> fan_triangulation_smooth(const std::vector<Tuple>& v, const std::vector<Tuple>& n) {
-    std::vector<Shape> t;  // src/obj_file.rs:153-162
-    for (size_t i = 2; i + 1 < v.size(); ++i)
-        t.push_back(Shape::SmoothTriangle(v[1], v.at(i), v.at(i + 1), n.at(1), n.at(i), n.at(i + 1)));
-    return t;
-}
 template <class T>
 static const T& idx(const std::vector<T>& v, size_t i) {
     if (i >= v.size()) throw Panic("index out of bounds");
     return v[i];
 }
 
-Parser parse_obj_file(const std::string& data) {  // src/obj_file.rs:29-141
-    Parser p;
-    p.vertices.push_back(ORIGIN);
-    p.normals.push_back(Tuple::vector(0., 0., 0.));
-    p.groups.push_back(Shape::Group());
+// The record loop of parse_obj_file (src/obj_file.rs:29-141).  What a face becomes goes to `sink`, so that the Shape
+// tree (parse_obj_file) and the packed form (obj_file_to_group) come from the same code and draw the same ids.
+template <class Sink>
+static void parse_obj_records(const std::string& data, std::vector<Tuple>& vertices, std::vector<Tuple>& normals, int& lines_ignored,
+                              Sink& sink) {
+    vertices.push_back(ORIGIN);
+    normals.push_back(Tuple::vector(0., 0., 0.));
+    sink.group();
     size_t pos = 0;
+    const std::string_view text(data);
+    std::vector<std::string_view> record;
+    std::vector<size_t> points, vertex_normals;
     while (pos < data.size()) {  // str::lines(): split on \n, strip one trailing \r
-        size_t nl = data.find('\n', pos);
-        std::string line = data.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
-        pos = (nl == std::string::npos) ? data.size() : nl + 1;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        std::vector<std::string> record = split_whitespace(line);
-        if (record.empty()) { p.lines_ignored += 1; continue; }
+        size_t nl = text.find('\n', pos);
+        std::string_view line = text.substr(pos, nl == std::string_view::npos ? std::string_view::npos : nl - pos);
+        pos = (nl == std::string_view::npos) ? data.size() : nl + 1;
+        if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+        split_whitespace(line, record);
+        if (record.empty()) { lines_ignored += 1; continue; }
         if (record[0] == "v" || record[0] == "vn") {
             if (record.size() < 4) throw Panic("range end index 4 out of range for slice");
             double c[3];
             bool ok = true;
             for (int k = 0; k < 3 && ok; ++k) ok = parse_f64(record[size_t(k) + 1], c[k]);
             if (!ok) continue;
-            if (record[0] == "v") p.vertices.push_back(Tuple::point(c[0], c[1], c[2]));
-            else p.normals.push_back(Tuple::vector(c[0], c[1], c[2]));
+            if (record[0] == "v") vertices.push_back(Tuple::point(c[0], c[1], c[2]));
+            else normals.push_back(Tuple::vector(c[0], c[1], c[2]));
         } else if (record[0] == "f") {
-            std::vector<size_t> points, vertex_normals;
+            points.clear();
+            vertex_normals.clear();
             bool contains_vertex_normal = false, bad = false;
             for (size_t r = 1; r < record.size() && !bad; ++r) {
-                const std::string& rec = record[r];
+                const std::string_view rec = record[r];
                 size_t start = 0, field = 0;
                 while (true) {
                     size_t slash = rec.find('/', start);
-                    std::string val = rec.substr(start, slash == std::string::npos ? std::string::npos : slash - start);
+                    std::string_view val = rec.substr(start, slash == std::string_view::npos ? std::string_view::npos : slash - start);
                     if (!val.empty()) {
                         size_t v;
                         if (!parse_usize(val, v)) { bad = true; break; }
                         if (field == 0) points.push_back(v);
                         else if (field == 2) { contains_vertex_normal = true; vertex_normals.push_back(v); }
                     }
-                    if (slash == std::string::npos) break;
+                    if (slash == std::string_view::npos) break;
                     start = slash + 1;
                     ++field;
                 }
             }
             if (bad) continue;
-            Shape& group = p.groups.back();
             if (contains_vertex_normal) {
-                if (points.size() > 3) {
-                    for (Shape& t : fan_triangulation_smooth(p.vertices, p.normals)) group.add_child(t);
+                if (points.size() > 3) {  // fan_triangulation_smooth over the WHOLE vertex list (F3), src/obj_file.rs:153-162
+                    sink.begin_fan();
+                    for (size_t i = 2; i + 1 < vertices.size(); ++i)
+                        sink.smooth(vertices[1], vertices.at(i), vertices.at(i + 1), normals.at(1), normals.at(i), normals.at(i + 1));
+                    sink.end_fan();
                 } else {
-                    Shape t = Shape::SmoothTriangle(idx(p.vertices, idx(points, 0)), idx(p.vertices, idx(points, 1)),
-                                                    idx(p.vertices, idx(points, 2)), idx(p.normals, idx(vertex_normals, 0)),
-                                                    idx(p.normals, idx(vertex_normals, 1)), idx(p.normals, idx(vertex_normals, 2)));
-                    group.add_child(t);
+                    sink.begin_fan();
+                    sink.smooth(idx(vertices, idx(points, 0)), idx(vertices, idx(points, 1)), idx(vertices, idx(points, 2)),
+                                idx(normals, idx(vertex_normals, 0)), idx(normals, idx(vertex_normals, 1)), idx(normals, idx(vertex_normals, 2)));
+                    sink.end_fan();
                 }
             } else {
-                if (points.size() > 3) {
-                    for (Shape& t : fan_triangulation(p.vertices)) group.add_child(t);
+                if (points.size() > 3) {  // fan_triangulation over the WHOLE vertex list (F3), src/obj_file.rs:143-151
+                    sink.begin_fan();
+                    for (size_t i = 2; i + 1 < vertices.size(); ++i) sink.triangle(vertices[1], vertices[i], vertices[i + 1]);
+                    sink.end_fan();
                 } else {
-                    Shape t = Shape::Triangle(idx(p.vertices, idx(points, 0)), idx(p.vertices, idx(points, 1)),
-                                              idx(p.vertices, idx(points, 2)));
-                    group.add_child(t);
+                    sink.begin_fan();
+                    sink.triangle(idx(vertices, idx(points, 0)), idx(vertices, idx(points, 1)), idx(vertices, idx(points, 2)));
+                    sink.end_fan();
                 }
             }
         } else if (record[0] == "g") {
-            p.groups.push_back(Shape::Group());
+            sink.group();
         } else {
-            p.lines_ignored += 1;
+            lines_ignored += 1;
         }
     }
+}
+
+Parser parse_obj_file(const std::string& data) {  // src/obj_file.rs:29-141
+    Parser p;
+    struct Sink {  // triangles of a face are all created first (each draws its id), then added to the current group
+        Parser& p;
+        std::vector<Shape> pending;
+        void group() { p.groups.push_back(Shape::Group()); }
+        void begin_fan() { pending.clear(); }
+        void triangle(const Tuple& a, const Tuple& b, const Tuple& c) { pending.push_back(Shape::Triangle(a, b, c)); }
+        void smooth(const Tuple& a, const Tuple& b, const Tuple& c, const Tuple& na, const Tuple& nb, const Tuple& nc) {
+            pending.push_back(Shape::SmoothTriangle(a, b, c, na, nb, nc));
+        }
+        void end_fan() {
+            for (Shape& t : pending) p.groups.back().add_child(t);
+        }
+    } sink{p, {}};
+    parse_obj_records(data, p.vertices, p.normals, p.lines_ignored, sink);
     return p;
 }
 
@@ -565,6 +634,52 @@ Shape obj_to_group(Parser&& parser) {  // src/obj_file.rs:164-172
     Shape main_group = Shape::Group();
     for (Shape& g : parser.groups) main_group.add_child(g);
     return main_group;
+}
+
+Shape obj_file_to_group(const std::string& data, int32_t counts[5]) {
+    auto mesh = std::make_shared<PackedMesh>();
+    struct Sink {
+        PackedMesh& m;
+        std::vector<PackedTri> pending;
+        void group() { m.groups.push_back(PackedGroup{generate_object_id(), {}}); }
+        void begin_fan() { pending.clear(); }
+        void triangle(const Tuple& a, const Tuple& b, const Tuple& c) {  // Triangle::new, src/triangle.rs:38-56
+            PackedTri t;
+            t.id = generate_object_id();
+            t.smooth = false;
+            t.p1 = a; t.p2 = b; t.p3 = c;
+            t.e1 = b - a;
+            t.e2 = c - a;
+            t.normal = t.e2.cross(t.e1).normalize();
+            pending.push_back(t);
+        }
+        void smooth(const Tuple& a, const Tuple& b, const Tuple& c, const Tuple& na, const Tuple& nb, const Tuple& nc) {
+            triangle(a, b, c);  // SmoothTriangle::new, src/smooth_triangle.rs:42-65: the same derived fields
+            pending.back().smooth = true;
+            pending.back().n1 = na; pending.back().n2 = nb; pending.back().n3 = nc;
+        }
+        void end_fan() { m.groups.back().tris.insert(m.groups.back().tris.end(), pending.begin(), pending.end()); }
+    } sink{*mesh, {}};
+    std::vector<Tuple> vertices, normals;
+    int lines_ignored = 0;
+    parse_obj_records(data, vertices, normals, lines_ignored, sink);
+    int32_t tris = 0;
+    mesh->id_first = mesh->groups.front().id;
+    mesh->id_last = mesh->id_first - 1;
+    for (const PackedGroup& g : mesh->groups) {
+        tris += int32_t(g.tris.size());
+        mesh->id_first = std::min(mesh->id_first, g.id);
+        mesh->id_last = std::max(mesh->id_last, g.id);
+        for (const PackedTri& t : g.tris) { mesh->id_first = std::min(mesh->id_first, t.id); mesh->id_last = std::max(mesh->id_last, t.id); }
+    }
+    if (counts) {
+        counts[0] = lines_ignored;
+        counts[1] = int32_t(vertices.size());
+        counts[2] = int32_t(normals.size());
+        counts[3] = int32_t(mesh->groups.size());
+        counts[4] = tris;
+    }
+    return Shape::FromPackedMesh(std::move(mesh));  // obj_to_group: the main group's id is drawn last
 }
 
 // ---------------------------------------------------------------- canvas.rs

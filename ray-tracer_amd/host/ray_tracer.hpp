@@ -189,6 +189,25 @@ struct Bound {
 // ---------------------------------------------------------------- shape.rs + the shape modules
 enum class ShapeKind { Sphere = 0, Plane, Cube, Cylinder, Cone, Triangle, SmoothTriangle, Group, CSG };
 
+// Compact form of the Group tree parse_obj_file + obj_to_group build: one record per
+// triangle instead of one Shape (a Shape carries a Matrix, a Material and an optional Pattern, and Group::add_child
+// clones it).  Object ids are drawn in the order the reference draws them, so the flattened tables are the same, entry
+// for entry, as those of the Shape tree (tests/test_host_api.py compares them).  Immutable once built, shared by clones.
+struct PackedTri {
+    int id;
+    bool smooth;
+    Tuple p1, p2, p3, e1, e2, normal;  // as Triangle::new computes them (src/triangle.rs:38-56)
+    Tuple n1, n2, n3;                  // SmoothTriangle only
+};
+struct PackedGroup {  // one per `g` record, plus the parser's default group; identity transform, default material
+    int id;
+    std::vector<PackedTri> tris;
+};
+struct PackedMesh {
+    std::vector<PackedGroup> groups;
+    int id_first = 0, id_last = -1;  // the contiguous range of object ids drawn for groups and triangles
+};
+
 class Shape {
 public:
     // constructors: Sphere::new(), Plane::new(), ... each draws a fresh object id
@@ -227,6 +246,12 @@ public:
     std::optional<int> get_parent() const { return parent; }
     void set_parent(int p);
     const std::vector<Shape>& get_shapes() const;
+    // A Group made by obj_file_to_group keeps its children packed until something asks for them as Shapes
+    // (get_shapes, add_child, divide, includes, bounds_of ...): then they are materialised, ids and all.
+    const PackedMesh* packed() const { return packed_.get(); }
+    void unpack() const;
+    static Shape FromPackedMesh(std::shared_ptr<const PackedMesh> mesh);  // draws the main group's id
+    static Shape FromPackedTri(const PackedTri& t, int parent_id);
     void add_child(Shape& child);  // Group only
     bool includes(const Shape& other) const;
     Bound bounds_of() const;
@@ -245,15 +270,17 @@ public:
     bool closed = false;
     Tuple point1, point2, point3, edge_vector1, edge_vector2, normal_vector;  // Triangle / SmoothTriangle
     Tuple normal_vector1, normal_vector2, normal_vector3;                     // SmoothTriangle
-    std::vector<Shape> shapes;                                                // Group
+    mutable std::vector<Shape> shapes;                                        // Group (see unpack)
     std::string operation;                                                    // CSG
     std::unique_ptr<Shape> left, right;                                       // CSG
 
 private:
     Shape(ShapeKind k) : kind_(k), id_(generate_object_id()) {}
+    Shape(ShapeKind k, int id) : kind_(k), id_(id) {}  // a Shape that already has its id (unpack)
     void update_reference() const;  // Group::update_group_reference / CSG::update_csg_reference
     ShapeKind kind_;
     int id_;
+    mutable std::shared_ptr<const PackedMesh> packed_;
 };
 
 // The PARENT_REFERENCES registry (src/lib.rs:47-49), reduced to the fields ever read through it.
@@ -274,6 +301,9 @@ struct Parser {
 };
 Parser parse_obj_file(const std::string& data);
 Shape obj_to_group(Parser&& parser);
+// parse_obj_file + obj_to_group in one go with the children kept packed (same parser code, same ids, same registry
+// entries, same flattened tables; counts as Parser reports them: lines ignored, vertices, normals, groups, triangles)
+Shape obj_file_to_group(const std::string& data, int32_t counts[5] = nullptr);
 Shape hexagon();  // src/lib.rs:91-126
 
 // ---------------------------------------------------------------- canvas.rs

@@ -170,7 +170,7 @@ HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth
                 "rth_shape_set_minimum", "rth_shape_set_maximum", "rth_shape_set_closed", "rth_group_add_child",
                 "rth_shape_child_count", "rth_shape_child", "rth_shape_divide", "rth_shape_bounds_of",
                 "rth_shape_parent_space_bounds_of", "rth_shape_includes", "rth_shape_eq", "rth_triangle_data",
-                "rth_obj_to_group", "rth_world_create", "rth_world_free", "rth_world_flatten", "rth_world_scene",
+                "rth_obj_to_group", "rth_obj_file_to_group", "rth_world_create", "rth_world_free", "rth_world_flatten", "rth_world_scene",
                 "rth_camera_desc", "rth_canvas_to_ppm"]
 
 lib.rt_last_error.restype = C.c_char_p
@@ -249,6 +249,7 @@ lib.rth_shape_bounds_of.argtypes = [C.c_int, c_dp]
 lib.rth_shape_parent_space_bounds_of.argtypes = [C.c_int, c_dp]
 lib.rth_triangle_data.argtypes = [C.c_int, c_dp]
 lib.rth_obj_to_group.argtypes = [C.c_char_p, C.c_int64, c_ip]
+lib.rth_obj_file_to_group.argtypes = [C.c_char_p, C.c_int64, c_ip]
 lib.rth_world_create.argtypes = [c_ip, C.c_int, c_dp, c_dp, C.c_int]
 lib.rth_world_flatten.argtypes = [C.c_int]
 lib.rth_world_flatten.restype = C.POINTER(SceneDesc)
@@ -561,11 +562,16 @@ class Shape:
         return out.reshape(9, 3)
 
 
-def obj_to_group(text):
-    """parse_obj_file + obj_to_group (src/obj_file.rs:29-172).  Returns (main group, counts dict)."""
+def obj_to_group(text, packed=None):
+    """parse_obj_file + obj_to_group (src/obj_file.rs:29-172).  Returns (main group, counts dict).
+    packed (default: yes, unless RT_HOST_OBJ_SHAPES=1): the group keeps its triangles as packed records until something
+    asks for them as shapes (rth_obj_file_to_group) — same ids, same flattened tables, a fraction of the time."""
     raw = text.encode() if isinstance(text, str) else text
     counts = np.zeros(5, dtype=np.int32)
-    g = Shape(lib.rth_obj_to_group(raw, len(raw), counts.ctypes.data_as(c_ip)))
+    if packed is None:
+        packed = os.environ.get("RT_HOST_OBJ_SHAPES", "0") != "1"
+    fn = lib.rth_obj_file_to_group if packed else lib.rth_obj_to_group
+    g = Shape(fn(raw, len(raw), counts.ctypes.data_as(c_ip)))
     keys = ("lines_ignored", "vertices", "normals", "groups", "triangles")
     return g, dict(zip(keys, (int(c) for c in counts)))
 

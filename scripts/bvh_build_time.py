@@ -1,5 +1,5 @@
 """Scene creation time (program + BVH build + upload) with the host SAH build and with the GPU radix-tree topology
-(RT_AMD_DEVICE_BVH=1), and the render time each tree gives, on a synthetic mesh of N small triangles plus the headline
+(rt_scene_opts.device_bvh / RT_AMD_DEVICE_BVH=1: the whole tree on the device, rt_lbvh.hip), and the render time each tree gives, on a synthetic mesh of N small triangles plus the headline
 teapot scene.  usage: python scripts/bvh_build_time.py [N]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -592,9 +592,11 @@ def test_cull_ranges_are_not_trusted_from_very_far_away():
 
 
 def test_gpu_built_bvh_changes_nothing(monkeypatch):
-    """RT_AMD_DEVICE_BVH=1: meshes of 1024+ triangles take their tree topology from the GPU (Morton sort + binary radix
-    tree, csrc/rt_lbvh.hip).  A BVH only decides which triangles get tested: renders are bit-identical to those with the
-    host's SAH tree, lists and shadows match the oracle, and the scene reports that the GPU build was used."""
+    """rt_scene_opts.device_bvh / RT_AMD_DEVICE_BVH=1: meshes of 1024+ distinct triangles are built entirely on the GPU
+    (csrc/rt_lbvh.hip: Morton sort, binary radix tree, bottom-up boxes, leaves, BVH4 collapse).  A BVH only decides which
+    triangles get tested: renders are bit-identical to those with the host's SAH tree, lists and shadows match the
+    oracle, and the scene reports that the GPU build was used.  Also a 60k-triangle soup, and a mesh whose radix tree is
+    too deep for the traversal stack (the build declines, the host tree is used)."""
     w0, cam0 = scenes.teapot_scene(480, 270)
     plain = cam0.render(w0)
     assert rt.lib.rt_scene_meshes_built_on_gpu(w0.scene()) == 0
@@ -612,6 +614,46 @@ def test_gpu_built_bvh_changes_nothing(monkeypatch):
         assert np.array_equal(np.where(img.hit_id > 0, img.hit_id - shift, 0), ref.hit_id)
         assert np.array_equal(img.rgb, ref.rgb, equal_nan=True) and np.array_equal(img.flags, ref.flags)
         assert img.stats.total_rays == ref.stats.total_rays
+    def obj_world(lines, eye):
+        g, _ = rt.obj_to_group("\n".join(lines) + "\n")
+        g.set_material(Material(color=(0.8, 0.5, 0.3), reflective=0.2))
+        w = World()
+        w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+        w.objects.append(g)
+        cam = Camera(240, 135, math.pi / 3)
+        cam.transform = view_transform(eye, (0., 0.5, 0.), (0., 1., 0.))
+        return w, cam
+
+    def soup():
+        rng = np.random.default_rng(5)
+        n = 60000
+        p = rng.uniform(-4, 4, size=(n, 3))
+        p[:, 1] = np.abs(p[:, 1]) * 0.5
+        e = rng.uniform(-0.06, 0.06, size=(n, 2, 3))
+        v = np.stack([p, p + e[:, 0], p + e[:, 1]], axis=1).reshape(-1, 3)
+        return obj_world([f"v {a:.6f} {b:.6f} {c:.6f}" for a, b, c in v] + [f"f {3*i+1} {3*i+2} {3*i+3}" for i in range(n)], (0., 3., -9.))
+
+    def deep():  # centroids crowd towards one corner geometrically: a radix tree ~60 levels deep
+        lines, n = [], 1500
+        for i in range(n):
+            x = 4. * 0.97 ** i
+            lines += [f"v {x:.12f} {x:.12f} {x:.12f}", f"v {x * 1.01:.12f} {x:.12f} {x:.12f}", f"v {x:.12f} {x * 1.01:.12f} {x:.12f}"]
+        return obj_world(lines + [f"f {3*i+1} {3*i+2} {3*i+3}" for i in range(n)], (1., 2., -6.))
+
+    for make, expect_gpu in ((soup, 1), (deep, None)):
+        monkeypatch.setenv("RT_AMD_DEVICE_BVH", "1")
+        w1, cam1 = make()
+        img = cam1.render(w1, 3)
+        built = rt.lib.rt_scene_meshes_built_on_gpu(w1.scene())
+        assert expect_gpu is None or built == expect_gpu
+        monkeypatch.setenv("RT_AMD_DEVICE_BVH", "0")
+        w2, cam2 = make()
+        ref = cam2.render(w2, 3)
+        shift = int(img.hit_id[img.hit_id > 0].min()) - int(ref.hit_id[ref.hit_id > 0].min())
+        assert np.array_equal(np.where(img.hit_id > 0, img.hit_id - shift, 0), ref.hit_id)
+        assert np.array_equal(img.rgb, ref.rgb, equal_nan=True) and np.array_equal(img.flags, ref.flags)
+        print(make.__name__, "meshes built on the GPU:", built)
+    monkeypatch.setenv("RT_AMD_DEVICE_BVH", "1")
     w, cam = scenes.teapot_scene(96, 54)
     assert_image_parity(w, cam)
     assert rt.lib.rt_scene_meshes_built_on_gpu(w.scene()) == 1

@@ -277,3 +277,116 @@ def test_no_gpu_means_a_clear_error_not_a_fallback():
     with pytest.raises(rt.RtError) as e:
         w.scene()
     assert "no HIP device" in str(e.value) or "no CPU path" in str(e.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# OBJ -> flattened tables without a Shape per triangle (rth_obj_file_to_group)
+
+_TABLE_SIZES = {
+    "node_kind": ("n_nodes", 1), "node_object_id": ("n_nodes", 1), "node_parent": ("n_nodes", 1), "node_subtree_end": ("n_nodes", 1),
+    "node_xform": ("n_nodes", 1), "node_ancestor": ("n_nodes", 1), "node_material": ("n_nodes", 1), "node_casts_shadow": ("n_nodes", 1),
+    "node_eq_class": ("n_nodes", 1), "node_param": ("n_nodes", 1), "xform_inverse": ("n_xforms", 16), "xform_inverse_transpose": ("n_xforms", 16),
+    "ancestor_xform": ("n_ancestors", 1), "ancestor_parent": ("n_ancestors", 1), "group_box": ("n_groups", 6), "csg_op": ("n_csg", 1),
+    "conic_minimum": ("n_conics", 1), "conic_maximum": ("n_conics", 1), "conic_closed": ("n_conics", 1), "tri_p1": ("n_triangles", 3),
+    "tri_e1": ("n_triangles", 3), "tri_e2": ("n_triangles", 3), "tri_normal": ("n_triangles", 3), "tri_smooth": ("n_triangles", 1),
+    "smooth_n1": ("n_smooth", 3), "smooth_n2": ("n_smooth", 3), "smooth_n3": ("n_smooth", 3), "material_params": ("n_materials", 10),
+    "material_pattern": ("n_materials", 1), "pattern_kind": ("n_patterns", 1), "pattern_a": ("n_patterns", 3), "pattern_b": ("n_patterns", 3),
+    "pattern_inverse": ("n_patterns", 16), "light_position": ("n_lights", 3), "light_intensity": ("n_lights", 3)}
+
+
+def _tables(world):
+    d = world.flatten().contents
+    out = {}
+    for name, (count, width) in _TABLE_SIZES.items():
+        n = getattr(d, count) * width
+        out[name] = np.ctypeslib.as_array(getattr(d, name), shape=(n,)).copy() if n else np.zeros(0)
+    return out
+
+
+def _same_tables(a, b, what):
+    """Bit for bit, except that object ids (drawn from one global counter) may differ by renaming: the mapping between
+    the two id columns must be one-to-one."""
+    for name in _TABLE_SIZES:
+        x, y = a[name], b[name]
+        assert x.shape == y.shape, (what, name, x.shape, y.shape)
+        if name == "node_object_id":
+            fwd, back = {}, {}
+            for p, q in zip(x.tolist(), y.tolist()):
+                assert fwd.setdefault(p, q) == q and back.setdefault(q, p) == p, (what, "object ids are not a renaming")
+        else:
+            assert x.tobytes() == y.tobytes(), (what, name)
+
+
+def _obj_worlds(text, packed):
+    """The same constructions over a mesh parsed either way; each returns a World."""
+    from rt_amd import Light, Material, Shape, World, rotate, scale, translate
+    def mesh():
+        g, counts = rt.obj_to_group(text, packed=packed)
+        return g, counts
+    worlds = []
+    # 1: the mesh alone, transformed and with a material set on the main group
+    g, counts = mesh()
+    g.set_transform(translate(0.5, 0., -1.) * rotate(0.3, rt.Axis.Y) * scale(0.5, 0.5, 0.5))
+    g.set_material(Material(color=(0.2, 0.7, 0.4), reflective=0.3))
+    w = World(); w.lights.append(Light.point_light((-5., 8., -6.), rt.WHITE)); w.objects.append(g)
+    worlds.append(("alone", w))
+    # 2: between other shapes, and the SAME group twice in one world (equal ids: Shape::eq classes must be shared)
+    g, _ = mesh()
+    g.set_material(Material(color=(0.9, 0.1, 0.1), transparency=0.5, refractive_index=1.3))
+    w = World(); w.lights.append(Light.point_light((-5., 8., -6.), rt.WHITE))
+    w.objects += [Shape.sphere().set_transform(translate(3., 0., 0.)), g, Shape.plane(), g]
+    worlds.append(("twice", w))
+    # 3: as a CSG operand and inside another group
+    g, _ = mesh()
+    c = Shape.csg("difference", g, Shape.cube())
+    outer = Shape.group()
+    g2, _ = mesh()
+    g2.set_casts_shadow(False)
+    outer.add_child(g2)
+    outer.set_transform(scale(2., 2., 2.))
+    w = World(); w.lights.append(Light.point_light((-5., 8., -6.), rt.WHITE)); w.objects += [c, outer]
+    worlds.append(("csg+nested", w))
+    # 4: divided (needs the children as shapes: the packed form is materialised)
+    g, _ = mesh()
+    g.divide(4)
+    w = World(); w.lights.append(Light.point_light((-5., 8., -6.), rt.WHITE)); w.objects.append(g)
+    worlds.append(("divided", w))
+    return worlds, counts
+
+
+@pytest.mark.parametrize("asset", ["triangles.obj", "teapot-low.obj", "teapot.obj", "smooth", "random0", "random1", "random2", "quirks"])
+def test_packed_obj_groups_flatten_to_the_same_tables_as_shape_trees(asset):
+    import scenes
+    if asset == "smooth":
+        text = scenes.smooth_teapot_obj()
+    elif asset.startswith("random"):
+        text, _ = scenes.random_mesh_obj(np.random.RandomState(100 + int(asset[-1])))
+    elif asset == "quirks":  # several groups, an empty one, polygon faces (F3), ignored lines, a bad vertex, a vn-less slash form
+        text = "\n".join(["# comment", "v 0 0 0", "v 1 0 0", "v 1 1 0", "v x y z", "v 0 1 0", "v 0.5 2 0", "vn 0 0 1", "vn 0 1 0", "vn 1 0 0", "vn 0 0 -1", "vn 0 -1 0", "vn -1 0 0",
+                          "g first", "f 1 2 3", "f 1/5 2/6 3/7", "g empty", "g second", "f 1 2 3 4 5", "f 1//1 2//2 3//3",
+                          "f 1//1 2//2 3//3 4//1", "junk line", "f 2 3 4"]) + "\n"
+    else:
+        text = scenes.read_asset(asset)
+    shapes, counts_s = _obj_worlds(text, packed=False)
+    packed, counts_p = _obj_worlds(text, packed=True)
+    assert counts_s == counts_p
+    for (name, ws), (_, wp) in zip(shapes, packed):
+        _same_tables(_tables(ws), _tables(wp), (asset, name))
+
+
+def test_packed_obj_group_behaves_like_a_group_of_shapes():
+    """Everything the mirror lets a caller do with a parsed group works on the packed form (it is unpacked on demand)."""
+    import scenes
+    text = scenes.read_asset("triangles.obj")
+    a, _ = rt.obj_to_group(text, packed=False)
+    b, _ = rt.obj_to_group(text, packed=True)
+    assert np.array_equal(np.array(a.bounds_of()), np.array(b.bounds_of()), equal_nan=True)
+    b2, _ = rt.obj_to_group(text, packed=True)
+    first = lambda g: next(g.child(k).child(0) for k in range(g.child_count()) if g.child(k).child_count())
+    assert b2.includes(first(b2)) and not b2.includes(first(a))
+    assert b.child_count() == a.child_count()
+    for k in range(a.child_count()):
+        ga, gb = a.child(k), b.child(k)
+        assert ga.child_count() == gb.child_count()
+        for j in range(ga.child_count()):
+            assert np.array_equal(ga.child(j).triangle_data(), gb.child(j).triangle_data())
