@@ -974,8 +974,19 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     UP(upload(s, prog.node_nchain, &s->ds.node_nchain));
     {
         std::vector<NodeRec> recs(size_t(d.n_nodes));
-        for (size_t n = 0; n < recs.size(); ++n)
-            recs[n] = NodeRec{d.node_kind[n], d.node_param[n], prog.node_nchain[n], d.node_material[n]};
+        auto near_zero = [](double v) { return std::fabs(v - 0.) < EPS; };  // near_eq(v, 0.) as the kernels spell it
+        for (size_t n = 0; n < recs.size(); ++n) {
+            int bits = 0;
+            const int32_t mi = d.node_material[n];
+            if (mi >= 0 && d.node_kind[n] <= RT_SMOOTH_TRIANGLE) {
+                const double rf = d.material_params[size_t(mi) * RT_MAT_STRIDE + RT_MAT_REFLECTIVE];
+                const double tr = d.material_params[size_t(mi) * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
+                if (!near_zero(rf)) bits |= NODE_REFLECTS;
+                if (!near_zero(tr)) bits |= NODE_REFRACTS;
+                if (!near_zero(tr) || (rf > 0. && tr > 0.)) bits |= NODE_WALKS;
+            }
+            recs[n] = NodeRec{d.node_kind[n] | (bits << 8), d.node_param[n], prog.node_nchain[n], d.node_material[n]};
+        }
         UP(upload(s, recs, &s->ds.node_rec));
     }
     UP(upload(s, vec_of(d.node_casts_shadow, size_t(d.n_nodes)), &s->ds.node_casts_shadow));

@@ -34,8 +34,13 @@ constexpr int MAX_CHAIN = 16;     // transform levels above a leaf
 // What prepare_computations needs to know about the hit node, in one 16-byte fetch (the SoA columns below stay for
 // the kernels that need a single field).
 struct NodeRec {
-    int32_t kind, param, nchain, material;
+    int32_t kind;  // RT_* kind in bits 0-7; NODE_* bits of the node's material above
+    int32_t param, nchain, material;
 };
+// material predicates the ray-tree stage bits are made of (rt_kernels.hip.h: k_trace epilogue, needs_walk)
+constexpr int NODE_REFLECTS = 1;  // !near_eq(reflective, 0)                              src/world.rs:110
+constexpr int NODE_REFRACTS = 2;  // !near_eq(transparency, 0)                            src/world.rs:121
+constexpr int NODE_WALKS = 4;     // n1/n2 can be observed: NODE_REFRACTS, or reflective > 0 && transparency > 0 (schlick)
 static_assert(sizeof(NodeRec) == 16, "NodeRec must be 16 bytes");
 
 // Scene tables in HBM.  SoA per table; rows padded to what one lane fetches at once.

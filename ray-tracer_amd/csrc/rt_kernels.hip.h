@@ -1445,6 +1445,8 @@ __device__ __forceinline__ bool needs_walk(const DScene& S, double reflective, d
     if (remaining <= 0 && !S.walk_at_zero) return false;
     return !near_eq(transparency, 0.) || (reflective > 0. && transparency > 0.);
 }
+// the part of needs_walk that depends on the recursion level; the material's part is NODE_WALKS
+__device__ __forceinline__ bool needs_walk_at(const DScene& S, int remaining) { return !(remaining <= 0 && !S.walk_at_zero); }
 
 // Ray count of a level: known to the host (`n_dev` == null), or — when a whole frame is enqueued without a host
 // round trip per level — read from the previous level's CNT_NEXT, clamped to the capacity `n` the host passes instead.
@@ -1520,12 +1522,10 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long lon
             const int node = hit ? key >> 2 : 0;
             NodeRec rec = {0, 0, 0, 0};
             if (hit) rec = S.node_rec[node];
-            double reflective = 0., transparency = 0.;
-            if (hit) {
-                const double* __restrict__ m = S.mat + (size_t)rec.material * RT_MAT_STRIDE;
-                reflective = m[RT_MAT_REFLECTIVE];
-                transparency = m[RT_MAT_TRANSPARENCY];
-            }
+            // what the stage bits need to know about the hit's material rides in the record (NODE_* bits, set by the host
+            // with the device's own near_eq): one dependent look-up less per chunk
+            const int mbits = rec.kind >> 8;
+            rec.kind &= 0xff;
             double u = sink.bu, v = sink.bv;
             unsigned flags = alive ? sink.flags : 0;  // a NaN t panics the reference's sort whether or not anything is hit
             if (NEED_FIRST && hit && rec.kind == RT_SMOOTH_TRIANGLE) {
@@ -1542,9 +1542,9 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long lon
                 L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
                 L.ht[i] = sink.best_t;
                 stage = ST_HIT;
-                if (needs_walk(S, reflective, transparency, remaining)) stage |= ST_WALK;
-                if (!(near_eq(reflective, 0.) || remaining <= 0)) stage |= ST_REFLECT;      // src/world.rs:110
-                if (!(near_eq(transparency, 0.) || remaining <= 0)) stage |= ST_REFRACT;    // src/world.rs:121
+                if ((mbits & NODE_WALKS) && needs_walk_at(S, remaining)) stage |= ST_WALK;
+                if ((mbits & NODE_REFLECTS) && remaining > 0) stage |= ST_REFLECT;      // src/world.rs:110
+                if ((mbits & NODE_REFRACTS) && remaining > 0) stage |= ST_REFRACT;      // src/world.rs:121
             }
             if (i < n) {
                 L.hkey[i] = key;
