@@ -27,6 +27,7 @@
 #ifndef RT_ABI_H
 #define RT_ABI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -272,6 +273,14 @@ typedef struct rt_scene_opts {
  * rt_scene_create; opts NULL = all defaults. */
 int rt_scene_create_opts(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, const rt_scene_opts* opts,
                          rt_scene** out);
+
+/* Page-locked host memory for the output buffers of rt_render / rt_render_multi (no counterpart in the reference: it is
+ * what `vec![0f64; n]` becomes in Camera::render_gpu).  The D2H copy of a frame into pageable memory is staged by the HIP
+ * runtime at ~17 GB/s; into memory from rt_host_alloc it is one DMA at PCIe rate: rt_render of the 1920x1080 headline
+ * frame takes 2.65 ms instead of 4.65 ms (49.8 MB of f64 RGB).  Any host pointer works for every entry point; this one
+ * is just faster.  rt_host_free(NULL) is a no-op. */
+int rt_host_alloc(size_t bytes, void** out);
+void rt_host_free(void* p);
 
 /* Free everything rt_scene_create and later renders allocated for this scene. */
 void rt_scene_destroy(rt_scene* scene);

@@ -1117,6 +1117,18 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
 }
 }  // namespace
 
+int rt_host_alloc(size_t bytes, void** out) {
+    if (!out) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (rt_device_count() <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return RT_OK;
+}
+
+void rt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (MultiState* ms = s->multi) {  // the owner of a multi-GPU scene takes its replicas with it

@@ -160,7 +160,7 @@ class CMaterial(C.Structure):  # rth_material
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
                "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
-               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi",
+               "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi", "rt_host_alloc", "rt_host_free",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
                 "rth_matmul", "rth_inverse", "rth_material_default", "rth_shape_new", "rth_glass_sphere",
@@ -200,6 +200,30 @@ lib.rt_canvas_to_ppm_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_
                                          C.c_void_p, C.c_void_p]
 lib.rt_canvas_to_ppm_noalloc.restype = C.c_int64
 lib.rt_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.c_int32, c_ip, C.POINTER(C.c_void_p)]
+
+
+lib.rt_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+lib.rt_host_free.argtypes = [C.c_void_p]
+lib.rt_host_free.restype = None
+
+
+def pinned_array(shape, dtype=np.float64):
+    """A numpy array over page-locked host memory from rt_host_alloc (freed with the array): the fast target for
+    rt_render's host output buffers."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _chk(lib.rt_host_alloc(n, C.byref(p)))
+
+    class _Owner:
+        def __init__(self, ptr): self.ptr = ptr
+        def __del__(self):
+            try: lib.rt_host_free(self.ptr)
+            except Exception: pass
+    raw = (C.c_char * max(n, 1)).from_address(p.value)
+    raw._owner = _Owner(p)   # keeps the allocation alive as long as any view of `raw` exists
+    a = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    a[...] = 0
+    return a
 
 
 class SceneOpts(C.Structure):

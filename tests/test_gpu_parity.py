@@ -961,3 +961,21 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
         rc = rt.lib.rt_scene_create_opts(w.flatten(), 1, None, C.byref(bad), C.byref(h))
         if rc < 0:
             raise rt.RtError(int(rc), rt.last_error())
+
+
+@pytest.mark.gpu
+def test_rt_host_alloc_buffers_receive_the_same_frame():
+    """rt_host_alloc / rt_host_free: page-locked output buffers for rt_render are a faster target, not a different one."""
+    w, cam = scenes.teapot_scene(160, 90)
+    ref = cam.render(w)
+    rgb = rt.pinned_array((cam.vsize, cam.hsize, 3))
+    ids = rt.pinned_array((cam.vsize, cam.hsize), np.int32)
+    cd = cam.desc()
+    opts = rt.RenderOpts(max_depth=5, rank=0, n_ranks=1, want_counters=0, stream=None)
+    assert rt.lib.rt_render(w.scene(), C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), ids.ctypes.data_as(rt.c_ip), None, None) == 0
+    assert np.array_equal(rgb, ref.rgb) and np.array_equal(ids, ref.hit_id)
+    p = C.c_void_p()
+    assert rt.lib.rt_host_alloc(0, C.byref(p)) == 0 and p.value
+    rt.lib.rt_host_free(p)
+    rt.lib.rt_host_free(None)
+    assert rt.lib.rt_host_alloc(16, None) < 0
