@@ -119,6 +119,7 @@ struct rt_scene {
     hipGraphExec_t graph_exec = nullptr;
     std::string graph_key;
     bool use_graph = true;
+    bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
     int n_cus = 1;
@@ -575,6 +576,7 @@ int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sy
 // once when the queues exist, else (or when one overflowed) the level-by-level walk that sizes them.
 int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, rt_stats* stats) {
     if (D < 0) D = 0;  // color_at with remaining <= 0 still traces and shades the ray itself (src/world.rs:81-90)
+    if (!s->spawns) D = 0;  // no material reflects or refracts: levels 1.. would be empty launches (a third of C2's frame)
     int rc = ensure_counters(s, D + 2);
     if (rc != RT_OK) return rc;
     Timer tm{s, st, stats != nullptr};
@@ -657,7 +659,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         stats->rays_primary = n_valid;
     }
     if (n_slots == 0) return RT_OK;
-    const int D = opts->max_depth < 0 ? 0 : opts->max_depth;
+    const int D = opts->max_depth < 0 || !s->spawns ? 0 : opts->max_depth;  // see run_levels
     if ((rc = ensure_level(s, 0, n_slots)) != RT_OK || (rc = ensure_counters(s, D + 2)) != RT_OK) return rc;
     auto raygen = [&]() { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots); };
     auto output = [&]() {
@@ -985,6 +987,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
                 if (!near_zero(tr)) bits |= NODE_REFRACTS;
                 if (!near_zero(tr) || (rf > 0. && tr > 0.)) bits |= NODE_WALKS;
             }
+            if (bits) s->spawns = true;  // any of NODE_REFLECTS, NODE_REFRACTS, NODE_WALKS
             recs[n] = NodeRec{d.node_kind[n] | (bits << 8), d.node_param[n], prog.node_nchain[n], d.node_material[n]};
         }
         UP(upload(s, recs, &s->ds.node_rec));
