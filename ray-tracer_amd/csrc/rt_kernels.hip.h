@@ -113,6 +113,11 @@ struct ClosestSink {
     // the one the BVH leaf carries, so this sink has no use for the repeats.
     static constexpr bool WANTS_DUPS = false;
     __device__ __forceinline__ bool done() const { return best_t < stop_below; }
+    // intersections[0] is the SMALLEST t of the whole line, i.e. the farthest hit behind the origin: once one is known
+    // at first_t < 0, nothing with first_t < t < 0 can matter any more (it is neither the first entry nor a hit), so BVH
+    // boxes that lie wholly inside that gap are skipped (bvh_traverse)
+    static constexpr bool HAS_GAP = NEED_FIRST;
+    __device__ __forceinline__ double gap_lo() const { return first_t; }
     __device__ __forceinline__ double lo() const { return NEED_FIRST ? -INFINITY : 0.; }
     __device__ __forceinline__ double lo_mesh() const { return lo(); }
     __device__ __forceinline__ void emit_mesh(double t, int key, double u, double v, int uv) { emit(t, key, u, v, uv); }
@@ -131,6 +136,8 @@ struct ClosestSink {
 // Everything with t <= limit or near_eq(t, limit), kept as an unsorted bounded list (sorted by the caller).
 struct ListSink {
     static constexpr bool FAR_FIRST = false;
+    static constexpr bool HAS_GAP = false;
+    __device__ __forceinline__ double gap_lo() const { return 0.; }
     static constexpr bool WANTS_DUPS = true;
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ double lo_mesh() const { return lo(); }
@@ -163,6 +170,8 @@ struct ListSink {
 // line into a pruned search (boxes that end below the best entry so far are skipped, far children first).
 struct WalkSink {
     static constexpr bool FAR_FIRST = true;
+    static constexpr bool HAS_GAP = false;
+    __device__ __forceinline__ double gap_lo() const { return 0.; }
     static constexpr bool WANTS_DUPS = true;
     __device__ __forceinline__ bool done() const { return false; }
     double* t;    // [LIST_CAP], private
@@ -508,8 +517,9 @@ __device__ __forceinline__ RayF make_rayf(V3 o, V3 inv) {
            fabsf(r.iz) < 3e38f && r.budget < 3e38f;  // NaN fails every comparison
     return r;
 }
+template <bool GAP = false>
 __device__ __forceinline__ bool bvh_box_f32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r, float tlo,
-                                            float thi, float& tnear) {
+                                            float thi, float& tnear, float gap_lo = 0.f) {
     const float ax = (lox - r.ox) * r.ix, bx = (hix - r.ox) * r.ix;
     const float ay = (loy - r.oy) * r.iy, by = (hiy - r.oy) * r.iy;
     const float az = (loz - r.oz) * r.iz, bz = (hiz - r.oz) * r.iz;
@@ -519,6 +529,8 @@ __device__ __forceinline__ bool bvh_box_f32(float lox, float loy, float loz, flo
     tnear = tmin - slack;
     // a product that overflowed f32 is not an exact infinity: no culling on it
     if (!(slack < 3e38f)) return true;
+    // gap_lo < 0: the box is also skipped when it lies wholly inside (gap_lo, 0) — see ClosestSink::gap_lo
+    if (GAP && tmin - slack > gap_lo && tmax + slack < 0.f) return false;
     return !(tmin > tmax + slack) && !(tmax + slack < tlo) && !(tmin - slack > thi);
 }
 
@@ -590,10 +602,12 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
             float tn[4];
             if (rf.ok) {
                 const float tlo_f = __double2float_rd(tlo), thi_f = __double2float_ru(thi);
+                // rounded up: the gap only ever shrinks (no gap when the sink has none, inside CSG, or nothing behind yet)
+                const float gap_f = Sink::HAS_GAP && !full_line ? fminf(__double2float_ru(sink.gap_lo()), 0.f) : 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {  // all four tests run unconditionally: no branch per child
                     float t;
-                    bool hit = bvh_box_f32(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t) &
+                    bool hit = bvh_box_f32<Sink::HAS_GAP>(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t, gap_f) &
                                (ch[c] != INT32_MIN);
                     tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
                     if (!hit) ch[c] = INT32_MIN;

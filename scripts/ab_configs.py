@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, pkg)); sys.path.insert(0, os.path.join(ROO
 import torch
 import rt_amd as rt, scenes
 cases = [("C2 teapot_low", scenes.teapot_low, (1920, 1080), 5), ("C3 teapot", scenes.teapot_scene, (1920, 1080), 5),
+         ("C3s smooth", lambda w, h: scenes.teapot_scene(w, h, obj_text=scenes.smooth_teapot_obj()), (1920, 1080), 5),
          ("C4 mixed", scenes.mixed_scene, (2560, 1440), 5), ("C5 grid4", lambda w, h: scenes.instanced_grid(w, h, grid=4), (7680, 4320), 8)]
 for name, b, (W, H), depth in cases:
     w, cam = b(W, H)
