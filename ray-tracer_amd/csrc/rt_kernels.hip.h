@@ -1779,7 +1779,13 @@ __global__ __launch_bounds__(BLOCK) void k_spawn(Level L, Level N, long long n_c
 // Bottom-up: shade_hit for every node of one level (src/world.rs:57-79) == Material::lighting over the lights (the
 // shadow flags are in by now), schlick, and the blend with the children's resolved colours in the reference's own
 // operand order; color_at's miss case -> BLACK.  Surface colour, coefficients and reflectance never leave registers.
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next,
+// Held to 128 VGPRs = 4 wavefronts per SIMD (the second launch-bound is HIP's minimum wavefronts per execution unit):
+// left alone the kernel takes 138 and runs 3; at 4 it spills 4 registers and is 6-8 % faster (same-box A/B), at 5, 6 and
+// 8 the spills (38 / 48 / 66 registers) make it 1.7x, 1.9x and 2.6x slower.
+#ifndef RT_SHADE_MIN_WAVES
+#define RT_SHADE_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(BLOCK, RT_SHADE_MIN_WAVES) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next,
                                                  unsigned long long* overflow_count) {
     const long long n = level_count(n_cap, n_dev);
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
