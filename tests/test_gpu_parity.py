@@ -953,6 +953,23 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
                     assert ms.gather_kind == 0
             finally:
                 ms.close()
+    # an older, shorter struct: fields beyond struct_size are not read (here they hold garbage)
+    w, cam = scenes.mixed_scene(96, 54)
+    ref = cam.render(w, depth=3)
+    short = rt.SceneOpts(cull_ranges=0, passive_triangles=0)
+    short.struct_size = 12
+    short.frame_graph, short.device_bvh, short.gather, short.verbose = 12345, -777, 99, 1
+    h = C.c_void_p()
+    assert rt.lib.rt_scene_create_opts(w.flatten(), 1, None, C.byref(short), C.byref(h)) == 0, rt.last_error()
+    try:
+        assert rt.lib.rt_scene_gather_kind(h) == 0 and rt.lib.rt_scene_gpu_count(h) == 1
+        cd = cam.desc()
+        opts = rt.RenderOpts(max_depth=3, rank=0, n_ranks=1, want_counters=0, stream=None)
+        rgb = np.zeros_like(ref.rgb)
+        assert rt.lib.rt_render(h, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), None, None, None) == 0
+        assert np.array_equal(rgb, ref.rgb)
+    finally:
+        rt.lib.rt_scene_destroy(h)
     with pytest.raises(rt.RtError):  # struct_size must be set
         bad = rt.SceneOpts()
         bad.struct_size = 0
