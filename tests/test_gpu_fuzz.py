@@ -158,8 +158,8 @@ def _same_image(a, b, shift_ids=False):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_worlds_on_every_render_path(seed, monkeypatch):
-    """One random world at a frame size that runs as two concurrent sub-frame chains: the level-by-level walk (with
-    rt_stats), the chained / graph-replayed path twice, a second camera on the same scene (new graph, queues that
+    """One random world at a frame size large enough for every path: the level-by-level walk (with
+    rt_stats), the whole-frame-enqueue / graph-replayed path twice, a second camera on the same scene (new graph, queues that
     may have to grow), three tile shards, and the scene rebuilt without cull ranges and with the GPU-built BVH all
     give the same frame — and that frame matches the oracle on a sparse pixel sample."""
     import math

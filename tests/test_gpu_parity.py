@@ -355,8 +355,8 @@ def test_full_size_properties_c3():
     assert a.stats.rays_primary == 1919 * 1079
     assert a.stats.rays_shadow == a.stats.shaded_nodes * len(w.lights)
     assert np.isfinite(a.rgb).all() and not a.flags.any()
-    # without rt_stats a frame this size runs as concurrent sub-frame chains on their own streams (first such frame
-    # sizes the chains' queues level by level, the next ones are enqueued whole): same pixels every time
+    # without rt_stats the first frame sizes the queues level by level, the next ones are enqueued whole and replayed
+    # as one HIP graph: same pixels every time
     for _ in range(3):
         c = cam.render(w, want_stats=False)
         assert np.array_equal(c.rgb, a.rgb) and np.array_equal(c.hit_id, a.hit_id) and np.array_equal(c.flags, a.flags)
