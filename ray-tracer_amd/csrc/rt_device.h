@@ -12,6 +12,9 @@ constexpr int BLOCK = 256;        // 4 wavefronts: streaming kernels
 #ifndef RT_TBLOCK
 #define RT_TBLOCK 1024
 #endif
+#ifndef RT_TWAVES
+#define RT_TWAVES 4   // wavefronts per SIMD the traversal kernels are held to (512 / RT_TWAVES VGPRs each)
+#endif
 #ifndef RT_LDS_NODE_CAP
 #define RT_LDS_NODE_CAP 895
 #endif

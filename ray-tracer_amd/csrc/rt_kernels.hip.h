@@ -1483,7 +1483,7 @@ __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(
 // twice.  Either part may be empty (n_cap == 0: shadow rays only — the launch after the last level; prev_counters ==
 // null: level 0).  Every wavefront alternates between the two chunk feeds until both are dry.
 template <int SC, bool NEED_FIRST, bool COUNT>
-__global__ __launch_bounds__(TBLOCK, 4) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
+__global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
                                                   unsigned long long* counters, Level P, unsigned long long* prev_counters) {
     const long long n = n_cap > 0 ? level_count(n_cap, n_dev) : 0;
     const long long n_shadow = prev_counters ? (long long)prev_counters[CNT_SHADOW_Q] * S.n_lights : 0;
@@ -1694,7 +1694,7 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
 // knows which refraction slots stay dead.  On the critical path of the ray tree (the refracted ray's direction needs
 // n1/n2), unlike the shadow rays, hence a launch of its own between k_queue and k_spawn.
 template <int SC, bool COUNT>
-__global__ __launch_bounds__(TBLOCK, 4) void k_walk(DScene S, Level L, unsigned long long* counters) {
+__global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_walk(DScene S, Level L, unsigned long long* counters) {
     const long long n_walk = (long long)counters[CNT_CONTAINER_Q];
     if (n_walk == 0) return;
     Feed walk_feed;
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_all(CameraParams c, long lon
 
 // Kernel: World::intersect_world as a sorted list per ray (rt_intersect_world).
 template <int SC>
-__global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const double* __restrict__ origins,
+__global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_list(DScene S, long long n, const double* __restrict__ origins,
                                                  const double* __restrict__ dirs, int max_hits, int32_t* count, double* t_out,
                                                  int32_t* id_out, uint8_t* flags_out) {
     constexpr bool BIG = (SC & SC_BIG) != 0;
@@ -1954,7 +1954,7 @@ __global__ __launch_bounds__(TBLOCK, 4) void k_list(DScene S, long long n, const
 
 // Kernel: World::is_shadowed for a batch of points (rt_is_shadowed).
 template <int SC>
-__global__ __launch_bounds__(TBLOCK, 4) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out,
+__global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_shadow_points(DScene S, long long n, const double* __restrict__ points, uint8_t* out,
                                                           uint8_t* flags_out) {
     Feed feed;
     const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
