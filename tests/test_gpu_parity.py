@@ -996,3 +996,61 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
     rt.lib.rt_host_free(p)
     rt.lib.rt_host_free(None)
     assert rt.lib.rt_host_alloc(16, None) < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_built_bvh_on_awkward_meshes(seed):
+    """rt_lbvh.hip against the host tree on meshes chosen to stress the radix tree: many triangles with one and the same
+    centroid (equal Morton codes: ties broken by position), triangles on a line or in a plane (degenerate centroid box),
+    sizes from 1e-4 to 10 in one mesh, exact duplicates, clusters.  Whatever the build does (use its tree, or decline),
+    the frame is the host tree's frame bit for bit."""
+    rng = np.random.RandomState(700 + seed)
+    n = int(rng.randint(1100, 4000))
+    kind = seed % 4
+    if kind == 0:      # all centroids (nearly) equal: fans around one point
+        c = np.zeros((n, 3)) + rng.uniform(-0.5, 0.5, size=3)
+        e = rng.normal(size=(n, 2, 3)) * rng.uniform(0.2, 2.0, size=(n, 1, 1))
+        p0 = c - (e[:, 0] + e[:, 1]) / 3.
+        v = np.stack([p0, p0 + e[:, 0], p0 + e[:, 1]], axis=1)
+    elif kind == 1:    # on a line / in a plane
+        t = rng.uniform(-4, 4, size=n)
+        c = np.stack([t, np.full(n, 0.5), np.zeros(n)], axis=1)
+        e = rng.uniform(-0.2, 0.2, size=(n, 2, 3))
+        e[:, :, 2] = 0.
+        v = np.stack([c, c + e[:, 0], c + e[:, 1]], axis=1)
+    elif kind == 2:    # sizes over five orders of magnitude, clusters
+        centres = rng.uniform(-3, 3, size=(6, 3))
+        c = centres[rng.randint(0, 6, size=n)] + rng.normal(size=(n, 3)) * 0.05
+        s = 10. ** rng.uniform(-4, 1, size=(n, 1, 1))
+        e = rng.normal(size=(n, 2, 3)) * s
+        v = np.stack([c, c + e[:, 0], c + e[:, 1]], axis=1)
+    else:              # a soup with a third of its triangles repeated exactly
+        c = rng.uniform(-3, 3, size=(n, 3))
+        e = rng.uniform(-0.3, 0.3, size=(n, 2, 3))
+        v = np.stack([c, c + e[:, 0], c + e[:, 1]], axis=1)
+        v[n // 3: 2 * (n // 3)] = v[: n // 3]
+    pts = v.reshape(-1, 3)
+    text = "\n".join([f"v {a!r} {b!r} {c!r}" for a, b, c in pts.tolist()] + [f"f {3*i+1} {3*i+2} {3*i+3}" for i in range(n)]) + "\n"
+
+    def build():
+        g, _ = rt.obj_to_group(text)
+        g.set_material(Material(color=(0.7, 0.5, 0.3), reflective=0.3))
+        w = World()
+        w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+        w.objects += [g, Shape.plane().set_transform(translate(0., -4.5, 0.))]
+        cam = Camera(120, 80, math.pi / 2.5)
+        cam.transform = view_transform((1., 2.5, -9.), (0., 0., 0.), (0., 1., 0.))
+        return w, cam
+
+    w, cam = build()
+    ref = cam.render(w, 3)
+    ms = rt.MultiScene(w, [0], device_bvh=1)
+    try:
+        img = ms.render(cam, depth=3)
+        built = rt.lib.rt_scene_meshes_built_on_gpu(ms.h)
+    finally:
+        ms.close()
+    assert np.array_equal(img.hit_id, ref.hit_id) and np.array_equal(img.rgb, ref.rgb, equal_nan=True) and np.array_equal(img.flags, ref.flags)
+    assert built in (0, 1)
+    print("kind", kind, "n", n, "built on the GPU:", built)
