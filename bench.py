@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_smooth", "teapot_low", "mixed", "book", "grid"])
     ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="N = 1 only: take the N > 1 code path (rt_render_shard, RCCL gather in a one-rank group, rt_assemble_strided)")
     ap.add_argument("--no-c5", action="store_true", help="skip the second workload (C5 grid 4 at 8K) reported for the scaling sweep")
     ap.add_argument("--cpu-stride", type=int, default=12)
     args = ap.parse_args()
@@ -126,8 +128,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.rehearse_sharded   # the multi-rank code path (also with one rank, as a rehearsal)
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     builders = {"teapot": scenes.teapot_scene, "teapot_low": scenes.teapot_low, "mixed": scenes.mixed_scene,
@@ -145,18 +149,18 @@ def main():
         # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
         # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
         # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
-        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 0)]
+        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if sharded else 0)]
         gather_done = [None, None]
         frame = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
         # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
-        gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+        gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and sharded) else None
         gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
         opts = rt.RenderOpts(max_depth=depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
-        torch_stream = torch.cuda.current_stream(dev).cuda_stream if world > 1 else None
+        torch_stream = torch.cuda.current_stream(dev).cuda_stream if sharded else None
         state = {"k": 0}
 
         def step(stats=None):
-            if world == 1:
+            if not sharded:
                 # one GPU: Camera::render straight into the row-major frame in HBM (rt_render_frame), one blocking call
                 rc = rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None,
                                             C.byref(stats) if stats is not None else None)
@@ -194,7 +198,7 @@ def main():
             step()
         barrier()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if sharded:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()) / steps * 1e3
 
@@ -203,12 +207,12 @@ def main():
         step(st)
         local = torch.tensor([st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes],
                              dtype=torch.int64, device=dev)
-        if world > 1:
+        if sharded:
             dist.all_reduce(local)
         return st, [int(x) for x in local.tolist()]
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -353,7 +357,7 @@ def main():
                                       "spheres + checkered floor, 1 light, %dx%d, depth %d" % (args.width, args.height, args.depth)
                           if args.scene == "teapot" else args.scene,
                           "scene": args.scene, "resolution": [args.width, args.height], "depth": args.depth,
-                          "parallelism": "tile-shard x%d, RCCL gather" % world if world > 1 else "single GPU"},
+                          "parallelism": "tile-shard x%d, RCCL gather" % world if sharded else "single GPU"},
                "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
                                   "total": total_rays, "shaded_nodes": rays[4]},
                "value_is": "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), scene resident before the "
@@ -368,7 +372,7 @@ def main():
                "c5_grid4_8k": c5, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
                "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
