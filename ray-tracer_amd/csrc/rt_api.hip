@@ -119,6 +119,7 @@ struct rt_scene {
     hipGraphExec_t graph_exec = nullptr;
     std::string graph_key;
     bool use_graph = true;
+    bool fuse_output = true;   // graph path: level 0's k_shade writes the shard / frame (RT_AMD_FUSE_OUTPUT=0: A/B)
     bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
@@ -369,7 +370,7 @@ bool levels_overflowed(rt_scene* s, int max_depth) {
 //     the caller — after waiting for the stream — sees it with levels_overflowed() and repeats the frame with the walk.
 // Either way the plain counters of every block are copied to h_counters at the end (stream-ordered).
 template <bool COUNT>
-int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, Timer& tm, rt_stats* stats) {
+int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, Timer& tm, rt_stats* stats, const OutArgs* out = nullptr) {
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, size_t(D + 2) * CNT_TOTAL * sizeof(unsigned long long), st));
     const bool shadows = s->n_lights > 0;
     std::vector<long long> count(size_t(D) + 1, 0);  // sync walk: exact ray count of each level
@@ -436,8 +437,13 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         const Level& N = d < last ? s->levels[size_t(d) + 1].L : L;
         const bool exact = d == 0 || sync;
         const unsigned long long* n_dev = exact ? nullptr : counter_block(s, d - 1) + CNT_NEXT;
-        hipLaunchKernelGGL(k_shade, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev, d < last ? 1 : 0,
-                           d == 0 ? counter_block(s, 0) + CNT_OVERFLOW : (unsigned long long*)nullptr);
+        unsigned long long* ovf = d == 0 ? counter_block(s, 0) + CNT_OVERFLOW : (unsigned long long*)nullptr;
+        if (d == 0 && out)  // level 0 writes the shard / frame itself: no k_output launch, no second pass over the colours
+            hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev,
+                               d < last ? 1 : 0, ovf, *out);
+        else
+            hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(count[size_t(d)])), dim3(BLOCK), 0, st, s->ds, L, N, count[size_t(d)], n_dev,
+                               d < last ? 1 : 0, ovf, OutArgs{});
     }
     tm.end();
     HIP_TRY(hipGetLastError());
@@ -681,8 +687,9 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 Timer off{s, st, false};
                 raygen();
-                int rcc = enqueue_levels<false>(s, st, n_slots, D, false, off, nullptr);
-                output();
+                const OutArgs fused{d_rgb, d_id, d_flags, c, frame ? 1 : 0};
+                int rcc = enqueue_levels<false>(s, st, n_slots, D, false, off, nullptr, s->fuse_output ? &fused : nullptr);
+                if (!s->fuse_output) output();
                 hipError_t ee = hipStreamEndCapture(st, &graph);
                 if (rcc != RT_OK || ee != hipSuccess || !graph) {
                     if (graph) (void)hipGraphDestroy(graph);
@@ -1115,6 +1122,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     }
     if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
     s->use_graph = knobs.graph;
+    if (const char* e = std::getenv("RT_AMD_FUSE_OUTPUT")) s->fuse_output = std::atoi(e) != 0;
     *out = s;
     return RT_OK;
 }

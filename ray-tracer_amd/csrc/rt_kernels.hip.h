@@ -1785,15 +1785,39 @@ __global__ __launch_bounds__(BLOCK) void k_spawn(Level L, Level N, long long n_c
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 4
 #endif
+// Where level 0's resolved colours go when k_shade writes them out itself (OUT: what k_output does, without its launch
+// and without reading the colours back): shard buffers (slot order) or, with `frame`, whole row-major frames.
+struct OutArgs {
+    double* rgb;
+    int32_t* hit_id;
+    uint8_t* flags;
+    CameraParams cam;
+    int frame;
+};
+__device__ __forceinline__ void write_output(const DScene& S, const OutArgs& O, long long i, double r, double g, double b, int key,
+                                             unsigned flags) {
+    long long o = i;
+    if (O.frame) {
+        int px, py;
+        if (!slot_to_pixel(O.cam, i, px, py)) return;
+        o = (long long)py * O.cam.hsize + px;
+    }
+    O.rgb[3 * o] = r; O.rgb[3 * o + 1] = g; O.rgb[3 * o + 2] = b;
+    if (O.hit_id) O.hit_id[o] = key >= 0 ? S.node_object_id[key >> 2] : 0;
+    if (O.flags) O.flags[o] = (uint8_t)flags;
+}
+template <bool OUT>
 __global__ __launch_bounds__(BLOCK, RT_SHADE_MIN_WAVES) void k_shade(DScene S, Level L, Level N, long long n_cap, const unsigned long long* n_dev, int has_next,
-                                                 unsigned long long* overflow_count) {
+                                                 unsigned long long* overflow_count, OutArgs O) {
     const long long n = level_count(n_cap, n_dev);
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const int key = L.hkey[i];
     if (key < 0) {  // miss -> BLACK
         L.cr[i] = 0.; L.cg[i] = 0.; L.cb[i] = 0.;
-        if (overflow_count && (L.flags[i] & RT_FLAG_LIST_OVERFLOW)) atomicAdd(overflow_count, 1ull);
+        const unsigned miss_flags = L.flags[i];
+        if (overflow_count && (miss_flags & RT_FLAG_LIST_OVERFLOW)) atomicAdd(overflow_count, 1ull);
+        if (OUT) write_output(S, O, i, 0., 0., 0., key, miss_flags);
         return;
     }
     const int stage = L.mode[i];
@@ -1834,6 +1858,7 @@ __global__ __launch_bounds__(BLOCK, RT_SHADE_MIN_WAVES) void k_shade(DScene S, L
     L.flags[i] = (uint8_t)flags;
     // a level-0 ray whose tree ran into a bounded list: the host traces those again with the BIG variants
     if (overflow_count && (flags & RT_FLAG_LIST_OVERFLOW)) atomicAdd(overflow_count, 1ull);
+    if (OUT) write_output(S, O, i, out.x, out.y, out.z, key, flags);
 }
 
 // Level-0 rays whose resolved flags carry RT_FLAG_LIST_OVERFLOW: their indices (any order) and rays, for the fix-up pass.
