@@ -962,6 +962,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     popts.build_device = device >= 0 && device < ndev0 ? device : -1;
     popts.device_bvh = knobs.device_bvh;
     popts.cull_ranges = knobs.cull;
+    if (const char* e = std::getenv("RT_AMD_SHARE_MESHES")) popts.share_meshes = std::atoi(e) != 0;
     popts.verbose = knobs.verbose;
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);
@@ -1088,17 +1089,9 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         for (int n = 0; n < d.n_nodes; ++n)
             if (d.node_kind[n] <= RT_SMOOTH_TRIANGLE && d.node_eq_class[n] >= 0) uses[d.node_eq_class[n]]++;
         bool unique = true;
-        for (const MeshTri& t : prog.mesh_tris) {
-            const int32_t c = d.node_eq_class[t.node];
+        for (int32_t n : prog.mesh_nodes) {  // every triangle of every mesh, shared trees' instances and repeats included
+            const int32_t c = d.node_eq_class[n];
             if (c >= 0 && uses[c] != 1) unique = false;
-        }
-        for (int32_t m = 0; unique && size_t(m) < prog.mesh_dups.size();) {  // [count, node...] lists of repeated triangles
-            const int32_t cnt = prog.mesh_dups[size_t(m)];
-            for (int32_t j = 1; j <= cnt; ++j) {
-                const int32_t c = d.node_eq_class[prog.mesh_dups[size_t(m + j)]];
-                if (c >= 0 && uses[c] != 1) unique = false;
-            }
-            m += cnt + 1;
         }
         s->ds.passive_mesh_tris = unique && knobs.passive ? 1 : 0;
     }

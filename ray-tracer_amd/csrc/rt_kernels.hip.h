@@ -559,7 +559,7 @@ __device__ __forceinline__ void cswap(float& ta, int& ca, float& tb, int& cb) {
 }
 
 template <bool COUNT, class Sink, class E>
-__device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, V3 o, V3 d, V3 inv, const Sink& sink,
+__device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, int node_base, V3 o, V3 d, V3 inv, const Sink& sink,
                                              bool full_line, Work& w, E&& e) {
     const RayF rf = make_rayf(o, inv);
     // A launch lasts as long as its slowest wavefront, and the slow ones are in here: let them issue first.
@@ -649,18 +649,19 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 pin(tb.p1); pin(tb.e1); pin(tb.e2); pin(tb.node); pin(tb.smooth);
                 const TriHit ha = tri_eval<COUNT>(o, d, ta.p1, ta.e1, ta.e2, true, w);
                 const TriHit hb = tri_eval<COUNT>(o, d, tb.p1, tb.e1, tb.e2, two, w);
-                if (ha.ok) e(ha.t, ta.node * 4, ha.u, ha.v, ta.smooth & 1);
-                if (hb.ok) e(hb.t, tb.node * 4, hb.u, hb.v, tb.smooth & 1);
+                // leaf records number their nodes relative to the mesh's group node (identical meshes share one tree)
+                if (ha.ok) e(ha.t, (node_base + ta.node) * 4, ha.u, ha.v, ta.smooth & 1);
+                if (hb.ok) e(hb.t, (node_base + tb.node) * 4, hb.u, hb.v, tb.smooth & 1);
                 // a hit on a repeated triangle counts once per node that carries it (rt_program.cpp: build_mesh) — for sinks
                 // that keep lists, and inside CSG subtrees, whose filter toggles on every entry
                 if ((Sink::WANTS_DUPS || full_line) && ((ha.ok && (ta.smooth >> 1)) || (hb.ok && (tb.smooth >> 1)))) {
                     if (ha.ok && (ta.smooth >> 1)) {
                         const int* __restrict__ dl = S.mesh_dups + (ta.smooth >> 1) - 1;
-                        for (int j = 1, c = dl[0]; j <= c; ++j) e(ha.t, dl[j] * 4, ha.u, ha.v, ta.smooth & 1);
+                        for (int j = 1, c = dl[0]; j <= c; ++j) e(ha.t, (node_base + dl[j]) * 4, ha.u, ha.v, ta.smooth & 1);
                     }
                     if (hb.ok && (tb.smooth >> 1)) {
                         const int* __restrict__ dl = S.mesh_dups + (tb.smooth >> 1) - 1;
-                        for (int j = 1, c = dl[0]; j <= c; ++j) e(hb.t, dl[j] * 4, hb.u, hb.v, tb.smooth & 1);
+                        for (int j = 1, c = dl[0]; j <= c; ++j) e(hb.t, (node_base + dl[j]) * 4, hb.u, hb.v, tb.smooth & 1);
                     }
                 }
             }
@@ -899,7 +900,7 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
             bump<COUNT>(w.box);
             if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo_mesh(), sink.hi(), tnear))
             {
-                bvh_traverse<COUNT>(S, M, it.a, o, d, inv, sink, full_line, w, out_mesh);
+                bvh_traverse<COUNT>(S, M, it.a, it.node, o, d, inv, sink, full_line, w, out_mesh);
             }
             continue;
         }

@@ -63,7 +63,8 @@ static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 // Triangle copy in BVH leaf order (what the traversal kernel streams).
 struct MeshTri {
     double p1[3], e1[3], e2[3];  // src/triangle.rs:17-21
-    int32_t node;                // leaf node index (emission order + shading look-ups)
+    int32_t node;                // leaf node index MINUS the group node of its mesh (ITEM_MESH.node): identical meshes
+                                 // share one tree; the traversal adds the base back (emission order + shading look-ups)
     int32_t smooth;              // bit 0: SmoothTriangle (keeps u,v);  bits 1..: 0, or 1 + offset into mesh_dups of
                                  // [count, node, ...] — further nodes with the bit-identical triangle (tested once)
 };
@@ -76,7 +77,9 @@ struct Program {
                                        // (registry chain of src/shape.rs:394-420, identities kept)
     std::vector<BvhNode> bvh;
     std::vector<MeshTri> mesh_tris;
-    std::vector<int32_t> mesh_dups;    // node lists of repeated triangles (MeshTri::smooth)
+    std::vector<int32_t> mesh_dups;    // node lists of repeated triangles (MeshTri::smooth), relative like MeshTri::node
+    std::vector<int32_t> mesh_nodes;   // every triangle node that lives in some mesh (all instances, repeats included)
+    int32_t meshes_shared = 0;         // ITEM_MESH items that took the tree of an earlier, identical mesh
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
     int32_t meshes_built_on_gpu = 0;   // meshes whose tree topology came from rt_lbvh.hip
@@ -96,6 +99,7 @@ struct ProgramOpts {
     int build_device = -1;
     bool device_bvh = false;
     bool cull_ranges = true;
+    bool share_meshes = true;   // groups with identical triangle content take one tree (RT_AMD_SHARE_MESHES=0: A/B)
     bool verbose = false;   // phase times of the compilation on stderr
 };
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts = ProgramOpts());
