@@ -313,6 +313,11 @@ int rt_render_shard(rt_scene* scene, const rt_camera_desc* camera, const rt_rend
  * read-back for SURVEY.md section 8(f) row 1. */
 int32_t rt_scene_meshes_built_on_gpu(const rt_scene* scene);
 
+/* How many triangle meshes of the scene took the BVH of an earlier mesh with identical content (the same OBJ text
+ * parsed again, a group cloned into several places: same triangles in the same order under their group) instead of
+ * getting a tree of their own.  No counterpart in the reference; read-back for tests and tools. */
+int32_t rt_scene_meshes_shared(const rt_scene* scene);
+
 /* Camera::render (src/camera.rs:62-74) with the Canvas left in DEVICE memory: d_rgb_frame [vsize*hsize*3] row-major
  * (Canvas::write_pixel layout, src/canvas.rs:25-27), d_hit_id_frame / d_flags_frame nullable [vsize*hsize].  The
  * pixels of shard opts->rank of opts->n_ranks are written where they belong in the frame, the never-rendered last row

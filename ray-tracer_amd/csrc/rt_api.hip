@@ -93,6 +93,7 @@ struct rt_scene {
     std::vector<void*> allocs;
     bool has_csg = false, has_smooth = false, any_transparent = false;
     int meshes_built_on_gpu = 0;
+    int meshes_shared = 0;
     int scene_class = 0;  // SC_CSG | SC_CULL: which traversal kernel variants this scene runs
     int n_lights = 0;
     std::vector<LevelStore> levels;
@@ -1102,6 +1103,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
                      d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),
                      (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0));
     s->meshes_built_on_gpu = prog.meshes_built_on_gpu;
+    s->meshes_shared = prog.meshes_shared;
     s->has_csg = prog.has_csg;
     s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0);
     s->has_smooth = prog.has_smooth;
@@ -1197,6 +1199,7 @@ int rt_render_shard(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
 }
 
 int32_t rt_scene_meshes_built_on_gpu(const rt_scene* s) { return s ? s->meshes_built_on_gpu : 0; }
+int32_t rt_scene_meshes_shared(const rt_scene* s) { return s ? s->meshes_shared : 0; }
 
 int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
                     uint8_t* d_flags_frame, rt_stats* stats) {

@@ -159,7 +159,7 @@ class CMaterial(C.Structure):  # rth_material
 
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
-               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
+               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
                "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi", "rt_host_alloc", "rt_host_free",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
@@ -184,6 +184,8 @@ lib.rt_render_shard.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Ren
                                 C.c_void_p, C.POINTER(Stats)]
 lib.rt_scene_meshes_built_on_gpu.argtypes = [C.c_void_p]
 lib.rt_scene_meshes_built_on_gpu.restype = C.c_int32
+lib.rt_scene_meshes_shared.argtypes = [C.c_void_p]
+lib.rt_scene_meshes_shared.restype = C.c_int32
 lib.rt_render_frame.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.POINTER(Stats)]
 lib.rt_assemble.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -665,6 +665,81 @@ def test_gpu_built_bvh_changes_nothing(monkeypatch):
     del plain
 
 
+def _repeated_mesh_world(hsize, vsize):
+    """One OBJ text parsed five times and cloned twice: top level (opaque, glass), under a transformed group, as either
+    operand of a CSG, and a clone in both operands of a union; a second text (smooth height field) parsed twice, alone
+    in groups.  Flat text: height field with repeated faces and a polygon face (F3), so the shared tree carries repeat
+    lists too."""
+    rng = np.random.RandomState(77)
+    flat, _ = scenes.random_mesh_obj(rng)
+    while True:
+        text, is_smooth = scenes.random_mesh_obj(rng)
+        if not is_smooth:
+            flat2 = text
+            break
+    def parsed(text, tr, material):
+        g, _ = rt.obj_to_group(text)
+        return g.set_transform(tr).set_material(material)
+    sm = lambda sx: scale(sx, sx, sx)
+    red = Material(color=(0.9, 0.3, 0.2), diffuse=0.7, specular=0.4, reflective=0.2)
+    glass = Material(color=(0.8, 0.9, 1.), diffuse=0.2, reflective=0.3, transparency=0.7, refractive_index=1.4)
+    green = Material(color=(0.2, 0.8, 0.3), specular=0.1)
+    w = World()
+    w.lights.append(Light.point_light((-8., 11., -9.), rt.WHITE))
+    w.lights.append(Light.point_light((9., 6., -4.), (0.4, 0.4, 0.5)))
+    w.objects.append(Shape.plane().set_transform(translate(0., -0.6, 0.)).set_material(
+        Material(reflective=0.3, pattern=Pattern.checkered(rt.WHITE, rt.BLACK))))
+    a1 = parsed(flat, translate(-6., 0., 0.) * sm(0.5), red)
+    w.objects.append(a1)
+    w.objects.append(parsed(flat, translate(0., 0.3, -1.) * rotate(0.7, Axis.Y) * sm(0.45), glass))
+    holder = Shape.group().set_transform(translate(6., 0.5, 1.) * rotate(-0.3, Axis.X))
+    holder.add_child(a1.clone().set_transform(sm(0.4)))           # same ids as a1
+    holder.add_child(Shape.sphere().set_transform(translate(0., 1.5, 0.) * sm(0.5)).set_material(glass))
+    w.objects.append(holder)
+    ball = Shape.sphere().set_transform(translate(0., 0.4, 0.) * sm(2.2)).set_material(green)
+    w.objects.append(Shape.csg("difference", parsed(flat, sm(0.5), red), ball).set_transform(translate(-3., 0., 5.)))
+    box = Shape.cube().set_transform(scale(2., 1., 2.)).set_material(glass)
+    w.objects.append(Shape.csg("intersection", box, parsed(flat, sm(0.5), green)).set_transform(translate(3., 0., 5.)))
+    m = parsed(flat, sm(0.4), glass)
+    w.objects.append(Shape.csg("union", m, m.clone().set_transform(translate(0.3, 0.2, 0.) * sm(0.4))).set_transform(translate(0., 0., 9.)))
+    w.objects.append(parsed(flat2, translate(-7., 0., 8.) * sm(0.4), red))   # a different text: a tree of its own
+    w.objects.append(parsed(flat2, translate(7., 0., 8.) * sm(0.4), glass))
+    cam = Camera(hsize, vsize, 1.1)
+    cam.transform = view_transform((0.5, 7., -13.), (0., 0.3, 3.), (0., 1., 0.))
+    return w, cam
+
+
+def test_identical_meshes_share_one_tree_and_change_nothing(monkeypatch):
+    """Groups with the same triangle content (the same OBJ text parsed again, or a clone) take the BVH of the first one
+    built (rt_program.cpp: build_mesh): leaf records number their nodes relative to the mesh's group node.  Pure
+    sharing of tables: renders with and without it are bit-identical, lists / colours / shadows match the oracle, and
+    the scene reports how many meshes took an existing tree."""
+    w1, cam1 = _repeated_mesh_world(480, 270)
+    shared = cam1.render(w1, 5)
+    n_shared = rt.lib.rt_scene_meshes_shared(w1.scene())
+    assert n_shared >= 8, n_shared   # 10 meshes of the first text (main group; some texts add a "loose" group), 2 of the second
+    monkeypatch.setenv("RT_AMD_SHARE_MESHES", "0")
+    w0, cam0 = _repeated_mesh_world(480, 270)
+    plain = cam0.render(w0, 5)
+    assert rt.lib.rt_scene_meshes_shared(w0.scene()) == 0
+    monkeypatch.delenv("RT_AMD_SHARE_MESHES")
+    shift = int(shared.hit_id[shared.hit_id > 0].min()) - int(plain.hit_id[plain.hit_id > 0].min())
+    assert np.array_equal(np.where(shared.hit_id > 0, shared.hit_id - shift, 0), plain.hit_id)
+    assert np.array_equal(shared.rgb, plain.rgb, equal_nan=True) and np.array_equal(shared.flags, plain.flags)
+    assert shared.stats.total_rays == plain.stats.total_rays and shared.stats.rays_container == plain.stats.rays_container
+    assert shared.stats.rays_refract > 1000 and shared.stats.rays_container > 1000
+    w, cam = _repeated_mesh_world(96, 54)
+    assert_image_parity(w, cam)
+    o, d = _random_rays(1500, 21, center=(0., 0.5, 4.), radius=11.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 256)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 256)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+    assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
+    g_rgb, g_id, g_fl = w.color_at_batch(o[:400], d[:400], 5)
+    o_rgb, o_id, o_fl = ob.color_at_batch(w, o[:400], d[:400], 5)
+    assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+
+
 def test_instrumented_counters_do_not_change_the_image():
     w, cam = scenes.teapot_scene(160, 90)
     a = cam.render(w)
