@@ -36,7 +36,10 @@ F_LIGHTING = 75       # Material::lighting per light (+ one powf)
 F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
 B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
 # bytes of level state read + written per ray by each stage (rt_device.h: Level columns touched)
-B_RAY_IO = {"k_trace": 48 + 17, "k_trace_hit": 56, "shadow": 4 + 48 + 1, "container": 4 + 64 + 16 + 4, "k_queue+k_spawn": 4 + 16 + 60, "k_shade": 4 + 4 + 72 + 16 + 1 + 24 + 24}
+# (k_trace: a primary ray is read from its columns, 48; a ray of levels 1.. is made from its tag and its parent's hit,
+# 4 + 76, and stored, 48, when it hits something)
+B_RAY_IO = {"k_trace": 48 + 17, "k_trace_spawned": 4 + 76 + 17, "k_trace_hit": 56, "k_trace_spawned_hit": 48, "shadow": 4 + 48 + 1,
+            "container": 4 + 64 + 16 + 4, "k_queue": 4 + 8 + 8, "k_shade": 4 + 4 + 72 + 16 + 1 + 24 + 24}
 
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
@@ -276,18 +279,22 @@ def main():
         # the three kinds of work apart (work_trace / work_shadow / work_container).
         w_tr = [a + b for a, b in zip(sc.work_trace, sc.work_shadow)]
         works = {"k_trace": w_tr, "k_walk": list(sc.work_container)}
-        ms = {"k_trace": ev["ms_trace"], "k_walk": ev["ms_collect"], "k_queue+k_spawn": ev["ms_shade"], "k_shade": ev["ms_resolve"]}
+        ms = {"k_trace": ev["ms_trace"], "k_walk": ev["ms_collect"], "k_queue": ev["ms_shade"], "k_shade": ev["ms_resolve"]}
         launches = {"k_trace": st.n_trace_launches, "k_walk": st.n_shadow_launches,
-                    "k_queue+k_spawn": 2 * st.n_trace_launches - 3, "k_shade": st.n_trace_launches - 1}
-        traced = st.rays_primary + st.rays_reflect + st.rays_refract
+                    "k_queue": st.n_trace_launches - 1, "k_shade": st.n_trace_launches - 1}
+        spawned = st.rays_reflect + st.rays_refract
+        traced = st.rays_primary + spawned
         flops = {k: work_flops(v) for k, v in works.items()}
-        flops["k_trace"] += st.shaded_nodes * F_PREPARE   # prepare_computations runs in k_trace's epilogue
-        flops["k_queue+k_spawn"] = st.rays_reflect * F_REFLECT + st.rays_refract * F_REFRACT
+        flops["k_trace"] += st.shaded_nodes * F_PREPARE   # prepare_computations runs in k_trace's epilogue,
+        flops["k_trace"] += st.rays_reflect * F_REFLECT + st.rays_refract * F_REFRACT   # the ray spawn where it fetches its rays
+        flops["k_queue"] = 0
         flops["k_shade"] = st.shaded_nodes * F_LIGHTING * n_lights + st.rays_refract * F_SCHLICK
-        nbytes = {"k_trace": work_bytes(works["k_trace"]) + traced * B_RAY_IO["k_trace"] + st.shaded_nodes * B_RAY_IO["k_trace_hit"] +
-                  st.rays_shadow * B_RAY_IO["shadow"],
+        # (hits of levels 1.. are not counted apart: the spawned rays' share of the shaded nodes prices their stored rays)
+        spawned_hits = st.shaded_nodes * spawned // max(traced, 1)
+        nbytes = {"k_trace": work_bytes(works["k_trace"]) + st.rays_primary * B_RAY_IO["k_trace"] + spawned * B_RAY_IO["k_trace_spawned"] +
+                  st.shaded_nodes * B_RAY_IO["k_trace_hit"] + spawned_hits * B_RAY_IO["k_trace_spawned_hit"] + st.rays_shadow * B_RAY_IO["shadow"],
                   "k_walk": work_bytes(works["k_walk"]) + st.rays_container * B_RAY_IO["container"],
-                  "k_queue+k_spawn": traced * B_RAY_IO["k_queue+k_spawn"], "k_shade": traced * B_RAY_IO["k_shade"]}
+                  "k_queue": traced * B_RAY_IO["k_queue"], "k_shade": traced * B_RAY_IO["k_shade"]}
         dom = max(("k_trace", "k_walk"), key=lambda k: ms[k])
         n_launch = max(launches[dom], 1)
         pmc = None

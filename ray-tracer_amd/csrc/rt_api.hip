@@ -121,6 +121,7 @@ struct rt_scene {
     std::string graph_key;
     bool use_graph = true;
     bool fuse_output = true;   // graph path: level 0's k_shade writes the shard / frame (RT_AMD_FUSE_OUTPUT=0: A/B)
+    bool fuse_spawn = true;    // k_trace makes the rays of levels 1.. as it fetches them (RT_AMD_FUSE_SPAWN=0: k_spawn launches, A/B)
     bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
@@ -195,6 +196,10 @@ int ensure_level(rt_scene* s, size_t idx, long long cap) {
     ls.cap = 0;
     long long c = cap + cap / 8 + 1024;
     c = (c + 63) & ~63ll;
+    if (c > (1ll << 30)) {  // slots and parent tags (2 * ray + kind) are 32-bit
+        rt_set_error("a level of %lld rays is beyond the 2^30 a queue can number", c);
+        return RT_ERR_UNSUPPORTED;
+    }
     const size_t nd = 18, ni = 6;
     const size_t nl = size_t(s->n_lights > 0 ? s->n_lights : 1);
     size_t bytes = size_t(c) * (nd * sizeof(double) + ni * sizeof(int32_t) + 1 + nl);
@@ -310,16 +315,16 @@ inline long long chunks_for(long long n) { return (n + 63) / 64; }  // small lau
 // the hits of level P queued in `prev` (null: none); `prev_upper` bounds P's hit count for the grid size.
 template <bool COUNT>
 int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, int remaining,
-                 unsigned long long* ctr, const Level& P, unsigned long long* prev, long long prev_upper) {
+                 unsigned long long* ctr, const Level& P, unsigned long long* prev, long long prev_upper, int from_parent) {
     const long long chunks = chunks_for(n) + (prev ? chunks_for(prev_upper * (s->n_lights > 0 ? s->n_lights : 1)) : 0);
     int rc = RT_OK;
     if (s->big) {  // overflow fix-up: one variant serves every scene class (rt_kernels.hip.h: SC_BIG)
         if (COUNT) { rt_set_error("internal: the BIG variants are not instrumented"); return RT_ERR_BAD_ARG; }
-        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev);
+        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent);
     }
-#define RT_CALL(SC)                                                                                                            \
-    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)    \
-                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev)
+#define RT_CALL(SC)                                                                                                                      \
+    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent)    \
+                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
     return rc;
@@ -336,15 +341,15 @@ int launch_walk(rt_scene* s, hipStream_t st, const Level& L, long long n_upper, 
 
 // k_queue with the tile size that suits the level (n: its ray count, or the capacity that bounds it)
 inline void launch_queue(hipStream_t st, const Level& L, long long n, const unsigned long long* n_dev, long long next_cap,
-                         unsigned long long* ctr) {
+                         unsigned long long* ctr, int32_t* next_tag) {
     // (with a device-side count `n` is the queue's capacity: deep levels then take the large tiles too — measured in graph
     // mode, 20-27 us per launch against 24-36 us with small tiles, whose many empty workgroups cost more than they spread)
     if (n > 1500000) {
         constexpr long long T = (long long)TILE_ITERS * BLOCK;
-        hipLaunchKernelGGL(k_queue<TILE_ITERS>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+        hipLaunchKernelGGL(k_queue<TILE_ITERS>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
     } else {
         constexpr long long T = (long long)TILE_ITERS_SMALL * BLOCK;
-        hipLaunchKernelGGL(k_queue<TILE_ITERS_SMALL>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr);
+        hipLaunchKernelGGL(k_queue<TILE_ITERS_SMALL>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
     }
 }
 
@@ -397,11 +402,13 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         const long long prev_upper = d > 0 ? (sync ? count[size_t(d) - 1] : (d == 1 ? n0 : s->levels[size_t(d) - 1].cap)) : 0;
         count[size_t(d)] = n_arg;
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper); if (rc != RT_OK) return rc; }
+        // the rays of levels 1.. are made by the k_trace that traces them, from the parent hits (RT_AMD_FUSE_SPAWN=0: by
+        // k_spawn after the level before)
+        { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper, d > 0 && s->fuse_spawn); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
         tm.begin(stats ? &stats->ms_shade : nullptr);
-        launch_queue(st, L, n_arg, n_dev, next_cap, ctr);
+        launch_queue(st, L, n_arg, n_dev, next_cap, ctr, N.hkey);
         tm.end();
         if (s->any_transparent && (remaining > 0 || s->ds.walk_at_zero)) {
             tm.begin(stats ? &stats->ms_collect : nullptr);
@@ -409,9 +416,10 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
             tm.end();
             if (stats) stats->n_shadow_launches++;
         }
-        if (remaining > 0) {
+        if (remaining > 0 && !s->fuse_spawn) {  // one lane per slot of the next level: at most 2 per ray of this one
+            const long long slots = std::min(2 * n_arg, next_cap);
             tm.begin(stats ? &stats->ms_shade : nullptr);
-            hipLaunchKernelGGL(k_spawn, dim3(blocks_for(n_arg)), dim3(BLOCK), 0, st, L, N, n_arg, n_dev);
+            hipLaunchKernelGGL(k_spawn, dim3(blocks_for(slots)), dim3(BLOCK), 0, st, L, N, slots, ctr + CNT_NEXT);
             tm.end();
         }
         HIP_TRY(hipGetLastError());
@@ -430,7 +438,7 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
     if (shadows) {  // the shadow rays of the last level that holds rays: a k_trace launch without a closest-hit part
         const Level& P = s->levels[size_t(last)].L;
         tm.begin(stats ? &stats->ms_trace : nullptr);
-        { int rc = launch_trace<COUNT>(s, st, P, 0, nullptr, 0, counter_block(s, last + 1), P, counter_block(s, last), count[size_t(last)]); if (rc != RT_OK) return rc; }
+        { int rc = launch_trace<COUNT>(s, st, P, 0, nullptr, 0, counter_block(s, last + 1), P, counter_block(s, last), count[size_t(last)], 0); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
     }
@@ -1120,6 +1128,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
     s->use_graph = knobs.graph;
     if (const char* e = std::getenv("RT_AMD_FUSE_OUTPUT")) s->fuse_output = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_AMD_FUSE_SPAWN")) s->fuse_spawn = std::atoi(e) != 0;
     *out = s;
     return RT_OK;
 }

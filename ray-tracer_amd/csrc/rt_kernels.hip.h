@@ -1475,6 +1475,38 @@ __device__ __forceinline__ long long level_count(long long n, const unsigned lon
 __device__ __forceinline__ V3 over_point_of(V3 point, V3 normal) { return vadd(point, vmul(normal, EPS)); }
 __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(point, vmul(normal, EPS)); }
 
+// reflected_color / refracted_color ray spawn (src/world.rs:109-137) for the slot k_queue reserved in the next level
+// and tagged with its parent (`tag` = 2 * parent ray + 1 for the refraction ray): the ray that color_at is called with.
+// Needs the parent's prepare_computations (k_trace) and, for a refraction ray, its n1/n2 walk (k_walk).  A refraction
+// slot whose parent ran into total internal reflection stays a dead ray (refracted_color returns BLACK, src/world.rs:
+// 128-130) and is unhooked from its parent.  Called by k_trace when it fetches the rays of a level (the spawn then
+// costs no launch and no pass over the level: its loads overlap traversal work), or by k_spawn.
+__device__ __forceinline__ void spawn_ray(const Level& P, int tag, V3& o, V3& d) {
+    const long long i = tag >> 1;
+    const V3 pd = mk(P.dx[i], P.dy[i], P.dz[i]);
+    const V3 point = mk(P.px[i], P.py[i], P.pz[i]), normal_vector = mk(P.nx[i], P.ny[i], P.nz[i]);
+    if (!(tag & 1)) {  // reflected_color, src/world.rs:109-118
+        o = over_point_of(point, normal_vector);
+        d = reflect(pd, normal_vector);  // reflect_vector, src/intersection.rs:52
+        return;
+    }
+    const int stage = P.mode[i];
+    if (stage & ST_TIR) {
+        P.child_refr[i] = -1;
+        return;  // o, d stay the caller's dead ray
+    }
+    // refracted_color, src/world.rs:120-137
+    const bool walked = stage & ST_WALK;
+    const double n1 = walked ? P.hu[i] : 0., n2 = walked ? P.hv[i] : 0.;
+    const V3 eye_vector = vneg(pd);
+    double n_ratio = n1 / n2;
+    double cos_i = dot(eye_vector, normal_vector);
+    double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
+    double cos_t = sqrt(1. - sin2_t);
+    d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
+    o = under_point_of(point, normal_vector);
+}
+
 // One launch = the closest-hit pass of level d (rays of L, `remaining` is the value color_at was called with at this
 // level) AND the shadow rays of level d-1 (hits of P, queued by k_queue(d-1) in `prev_counters`' block).  is_shadowed
 // feeds only Material::lighting (src/world.rs:57-66), which nothing downstream of the ray tree waits for: the rays of
@@ -1485,7 +1517,7 @@ __device__ __forceinline__ V3 under_point_of(V3 point, V3 normal) { return vsub(
 // null: level 0).  Every wavefront alternates between the two chunk feeds until both are dry.
 template <int SC, bool NEED_FIRST, bool COUNT>
 __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
-                                                  unsigned long long* counters, Level P, unsigned long long* prev_counters) {
+                                                  unsigned long long* counters, Level P, unsigned long long* prev_counters, int from_parent) {
     const long long n = n_cap > 0 ? level_count(n_cap, n_dev) : 0;
     const long long n_shadow = prev_counters ? (long long)prev_counters[CNT_SHADOW_Q] * S.n_lights : 0;
     if (n == 0 && n_shadow == 0) return;  // uniform over the grid: nothing staged, nothing fed
@@ -1501,8 +1533,12 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
         o = mk(dead_ray(), 0., 0.);  // padding slot / dead ray
         d = mk(0., 0., 1.);
         if (c >= 0 && i < n) {
-            o = mk(L.ox[i], L.oy[i], L.oz[i]);
-            d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            if (from_parent) {
+                spawn_ray(P, L.hkey[i], o, d);
+            } else {
+                o = mk(L.ox[i], L.oy[i], L.oz[i]);
+                d = mk(L.dx[i], L.dy[i], L.dz[i]);
+            }
         }
     };
     // the hit a lane's shadow ray belongs to: the queue's indirection is taken one chunk ahead too, so that a shadow
@@ -1556,6 +1592,10 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
                 L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
                 L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
                 L.ht[i] = sink.best_t;
+                if (from_parent) {  // a ray made here exists nowhere else: k_walk, k_shade and the next level's spawn read a HIT's ray
+                    L.ox[i] = o.x; L.oy[i] = o.y; L.oz[i] = o.z;
+                    L.dx[i] = d.x; L.dy[i] = d.y; L.dz[i] = d.z;
+                }
                 stage = ST_HIT;
                 if ((mbits & NODE_WALKS) && needs_walk_at(S, remaining)) stage |= ST_WALK;
                 if ((mbits & NODE_REFLECTS) && remaining > 0) stage |= ST_REFLECT;      // src/world.rs:110
@@ -1610,7 +1650,7 @@ struct TileSlots {
 
 template <int ITERS>
 __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const unsigned long long* n_dev, long long next_cap,
-                                                 unsigned long long* counters) {
+                                                 unsigned long long* counters, int32_t* __restrict__ next_tag) {
     constexpr int TILE = ITERS * BLOCK;
     const long long n = level_count(n_cap, n_dev);
     if ((long long)blockIdx.x * TILE >= n) return;  // whole workgroup beyond the level
@@ -1684,8 +1724,12 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
         if (i < n) {
             long long s0 = ts.base[2] + ts.off[2][it][wave] + __popcll(b2 & lanes_below());
             long long s1 = ts.base[2] + ts.off[3][it][wave] + __popcll(b3 & lanes_below());
-            L.child_refl[i] = (st & ST_REFLECT) && s0 < next_cap ? (int)s0 : -1;
-            L.child_refr[i] = (st & ST_REFRACT) && s1 < next_cap ? (int)s1 : -1;
+            const bool refl = (st & ST_REFLECT) && s0 < next_cap, refr = (st & ST_REFRACT) && s1 < next_cap;
+            L.child_refl[i] = refl ? (int)s0 : -1;
+            L.child_refr[i] = refr ? (int)s1 : -1;
+            // the slots name their parent (spawn_ray): the next level's hit-key column is free until its k_trace
+            if (refl) next_tag[s0] = (int32_t)(2 * i);
+            if (refr) next_tag[s1] = (int32_t)(2 * i + 1);
         }
     }
 }
@@ -1738,43 +1782,16 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_walk(DScene S, Level L, u
     if (COUNT) flush_work(w, counters + CNT_WC_XFORMS);
 }
 
-// reflected_color / refracted_color ray spawn (src/world.rs:109-137) into the slots k_queue reserved in the next
-// level.  One ray per lane, no atomics, no barriers.  Needs prepare_computations (k_trace) and, for a refraction
-// ray, the n1/n2 walk (k_walk) — not the shadow rays.
+// spawn_ray for every slot of the next level, as a launch of its own (RT_AMD_FUSE_SPAWN=0: the A/B of k_trace's fused
+// spawn).  One ray per lane, no atomics, no barriers.
 __global__ __launch_bounds__(BLOCK) void k_spawn(Level L, Level N, long long n_cap, const unsigned long long* n_dev) {
     const long long n = level_count(n_cap, n_dev);
-    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int stage = L.mode[i];
-    if (!(stage & (ST_REFLECT | ST_REFRACT))) return;
-    const int c0 = L.child_refl[i], c1 = L.child_refr[i];
-    if (c0 < 0 && c1 < 0) return;
-    const V3 d = mk(L.dx[i], L.dy[i], L.dz[i]);
-    const V3 point = mk(L.px[i], L.py[i], L.pz[i]), normal_vector = mk(L.nx[i], L.ny[i], L.nz[i]);
-    if (c0 >= 0) {  // reflected_color, src/world.rs:109-118
-        const V3 over_point = over_point_of(point, normal_vector);
-        const V3 refl_d = reflect(d, normal_vector);  // reflect_vector, src/intersection.rs:52
-        N.ox[c0] = over_point.x; N.oy[c0] = over_point.y; N.oz[c0] = over_point.z;
-        N.dx[c0] = refl_d.x; N.dy[c0] = refl_d.y; N.dz[c0] = refl_d.z;
-    }
-    if (c1 >= 0) {
-        if (stage & ST_TIR) {  // refracted_color returns BLACK (src/world.rs:128-130): the reserved slot is a dead ray
-            N.ox[c1] = dead_ray();
-            L.child_refr[i] = -1;
-        } else {  // refracted_color, src/world.rs:120-137
-            const bool walked = stage & ST_WALK;
-            const double n1 = walked ? L.hu[i] : 0., n2 = walked ? L.hv[i] : 0.;
-            const V3 eye_vector = vneg(d);
-            double n_ratio = n1 / n2;
-            double cos_i = dot(eye_vector, normal_vector);
-            double sin2_t = (n_ratio * n_ratio) * (1. - cos_i * cos_i);
-            double cos_t = sqrt(1. - sin2_t);
-            V3 refr_d = vsub(vmul(normal_vector, (n_ratio * cos_i - cos_t)), vmul(eye_vector, n_ratio));
-            V3 refr_o = under_point_of(point, normal_vector);
-            N.ox[c1] = refr_o.x; N.oy[c1] = refr_o.y; N.oz[c1] = refr_o.z;
-            N.dx[c1] = refr_d.x; N.dy[c1] = refr_d.y; N.dz[c1] = refr_d.z;
-        }
-    }
+    const long long c = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n) return;
+    V3 o = mk(dead_ray(), 0., 0.), d = mk(0., 0., 1.);
+    spawn_ray(L, N.hkey[c], o, d);
+    N.ox[c] = o.x; N.oy[c] = o.y; N.oz[c] = o.z;
+    N.dx[c] = d.x; N.dy[c] = d.y; N.dz[c] = d.z;
 }
 
 // Bottom-up: shade_hit for every node of one level (src/world.rs:57-79) == Material::lighting over the lights (the

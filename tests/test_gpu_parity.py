@@ -740,6 +740,35 @@ def test_identical_meshes_share_one_tree_and_change_nothing(monkeypatch):
     assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
 
 
+def test_rays_made_by_k_trace_equal_the_rays_k_spawn_writes(monkeypatch):
+    """Levels 1.. have no launch that writes their rays: k_queue tags each reserved slot with its parent and k_trace
+    makes the ray when it fetches the slot (spawn_ray; reflected_color / refracted_color, src/world.rs:109-137).
+    RT_AMD_FUSE_SPAWN=0 puts the k_spawn launch back (same spawn_ray, rays stored by a pass over the level): frames,
+    flags and ray counts are bit-identical, graph replay and level-by-level walk alike, on glass (total internal
+    reflection leaves dead slots), CSG and a mesh grid."""
+    for builder, size, depth in ((scenes.teapot_scene, (480, 270), 5), (scenes.mixed_scene, (640, 360), 5),
+                                 (lambda w, h: scenes.instanced_grid(w, h, grid=2), (480, 270), 8)):
+        w1, cam1 = builder(*size)
+        first = cam1.render(w1, depth)          # level-by-level walk (sizes the queues)
+        again = cam1.render(w1, depth)          # whole frame enqueued at once
+        replays = [cam1.render(w1, depth, want_stats=False) for _ in range(2)]  # captured as a graph, replayed
+        monkeypatch.setenv("RT_AMD_FUSE_SPAWN", "0")
+        w0, cam0 = builder(*size)
+        plain = cam0.render(w0, depth)
+        plain_again = cam0.render(w0, depth)
+        plain_replays = [cam0.render(w0, depth, want_stats=False) for _ in range(2)]
+        monkeypatch.delenv("RT_AMD_FUSE_SPAWN")
+        shift = int(first.hit_id[first.hit_id > 0].min()) - int(plain.hit_id[plain.hit_id > 0].min())
+        for a, b in ((first, plain), (again, plain_again), (again, first)):
+            assert np.array_equal(a.rgb, b.rgb, equal_nan=True) and np.array_equal(a.flags, b.flags)
+            assert (a.stats.rays_reflect, a.stats.rays_refract, a.stats.rays_shadow, a.stats.rays_container) == \
+                (b.stats.rays_reflect, b.stats.rays_refract, b.stats.rays_shadow, b.stats.rays_container)
+        for a in replays + plain_replays:
+            assert np.array_equal(a.rgb, first.rgb, equal_nan=True) and np.array_equal(a.flags, first.flags)
+        assert np.array_equal(np.where(first.hit_id > 0, first.hit_id - shift, 0), plain.hit_id)
+        assert first.stats.rays_reflect > 1000
+
+
 def test_instrumented_counters_do_not_change_the_image():
     w, cam = scenes.teapot_scene(160, 90)
     a = cam.render(w)
