@@ -976,7 +976,7 @@ struct Feed {
         n_real = chunks;
         cols = (chunks + FEED_ROWS - 1) / FEED_ROWS;
         n_chunks = cols * FEED_ROWS;
-        const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + (threadIdx.x >> 6);
+        const long long wave = (long long)blockIdx.x * (TBLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         next_static = wave;
         stride_static = (long long)gridDim.x * (TBLOCK / 64);
         // a launch with at most two chunks per wavefront has nothing to balance: deal statically, no atomics at all
@@ -1002,7 +1002,7 @@ struct Feed {
             const long long p = next_position();
             if (p < 0) return -1;
             const long long c = (p % FEED_ROWS) * cols + p / FEED_ROWS;
-            if (c < n_real) return c;
+            if (c < n_real) return (long long)uniform((unsigned long long)c);  // in scalar registers from here on
         }
     }
     __device__ __forceinline__ long long next_position() {
