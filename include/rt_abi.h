@@ -267,6 +267,13 @@ typedef struct rt_scene_opts {
     int32_t gather;             /* rt_render_multi: -1 RCCL when there is more than one device and it loads, else peer
                                    copies; 1 RCCL even for one device; 2 peer copies always        [RT_AMD_GATHER]     */
     int32_t verbose;            /* -1/0 quiet, 1 one line of scene statistics on stderr          [RT_AMD_VERBOSE]      */
+    /* (fields below: struct_size >= 40; a shorter struct leaves them at the default) */
+    int32_t share_meshes;       /* meshes with identical triangle content take one BVH: -1/1 yes, 0 a tree each
+                                                                                              [RT_AMD_SHARE_MESHES]    */
+    int32_t fuse_output;        /* level 0's shading pass writes the frame / shard itself: -1/1 yes, 0 a k_output launch
+                                                                                               [RT_AMD_FUSE_OUTPUT]    */
+    int32_t fuse_spawn;         /* the launch that traces a level makes its reflection / refraction rays: -1/1 yes, 0 a
+                                   k_spawn launch writes them first                             [RT_AMD_FUSE_SPAWN]    */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is

@@ -931,6 +931,7 @@ namespace {
 // rt_scene_opts with every -1 resolved: the field, else its RT_AMD_* variable, else the default
 struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
+    bool share_meshes = true, fuse_output = true, fuse_spawn = true;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
 };
 void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
@@ -947,6 +948,9 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     k.graph = pick(v.frame_graph, "RT_AMD_GRAPH", true);
     k.device_bvh = pick(v.device_bvh, "RT_AMD_DEVICE_BVH", false);
     k.verbose = pick(v.verbose, "RT_AMD_VERBOSE", false);
+    k.share_meshes = pick(v.share_meshes, "RT_AMD_SHARE_MESHES", true);
+    k.fuse_output = pick(v.fuse_output, "RT_AMD_FUSE_OUTPUT", true);
+    k.fuse_spawn = pick(v.fuse_spawn, "RT_AMD_FUSE_SPAWN", true);
     k.gather = v.gather == 1 || v.gather == 2 ? v.gather : -1;
     if (v.gather < 0)
         if (const char* e = std::getenv("RT_AMD_GATHER")) k.gather = std::strcmp(e, "rccl") == 0 ? 1 : std::strcmp(e, "peer") == 0 ? 2 : -1;
@@ -971,7 +975,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     popts.build_device = device >= 0 && device < ndev0 ? device : -1;
     popts.device_bvh = knobs.device_bvh;
     popts.cull_ranges = knobs.cull;
-    if (const char* e = std::getenv("RT_AMD_SHARE_MESHES")) popts.share_meshes = std::atoi(e) != 0;
+    popts.share_meshes = knobs.share_meshes;
     popts.verbose = knobs.verbose;
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);
@@ -1127,8 +1131,8 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     }
     if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
     s->use_graph = knobs.graph;
-    if (const char* e = std::getenv("RT_AMD_FUSE_OUTPUT")) s->fuse_output = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_AMD_FUSE_SPAWN")) s->fuse_spawn = std::atoi(e) != 0;
+    s->fuse_output = knobs.fuse_output;
+    s->fuse_spawn = knobs.fuse_spawn;
     *out = s;
     return RT_OK;
 }

@@ -1037,7 +1037,9 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
         w, cam = build(*size)
         ref = cam.render(w, depth=depth)
         for kw in ({"cull_ranges": 0}, {"passive_triangles": 0}, {"frame_graph": 0}, {"device_bvh": 1}, {"gather": 1},
-                   {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0}):
+                   {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0},
+                   {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0, "share_meshes": 0,
+                    "fuse_output": 0, "fuse_spawn": 0}):
             ms = rt.MultiScene(w, [0], **kw)
             try:
                 img = ms.render(cam, depth=depth)  # rt_render_multi (with rt_stats: plain launches)
@@ -1063,6 +1065,7 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
     short = rt.SceneOpts(cull_ranges=0, passive_triangles=0)
     short.struct_size = 12
     short.frame_graph, short.device_bvh, short.gather, short.verbose = 12345, -777, 99, 1
+    short.share_meshes, short.fuse_output, short.fuse_spawn = 7, -9, 31
     h = C.c_void_p()
     assert rt.lib.rt_scene_create_opts(w.flatten(), 1, None, C.byref(short), C.byref(h)) == 0, rt.last_error()
     try:
