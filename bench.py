@@ -95,8 +95,8 @@ def cpu_baseline_all_cores(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # 0.33 s of frames: long enough for the driver's GPU-activity sampler
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
@@ -265,11 +265,11 @@ def main():
         del job, step
         w5, cam5 = scenes.instanced_grid(7680, 4320, grid=4)
         job5 = make_job(w5, cam5, 8, 7680, 4320)
-        ms5 = timed(job5["step"], 5, 2)
+        ms5 = timed(job5["step"], 20, 3)
         _, rays5 = ray_counts(job5["step"])
         c5 = {"workload": "configs[4] geometry at grid 4: 16 instanced teapots (101,120 triangles) + floor, 7680x4320, depth 8",
               "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-              "steps": 5, "warmup": 2, "rays_per_frame": sum(rays5[:4]), "n_gpus": world}
+              "steps": 20, "warmup": 3, "rays_per_frame": sum(rays5[:4]), "n_gpus": world}
         del job5
 
     if rank == 0:
