@@ -345,11 +345,11 @@ inline void launch_queue(hipStream_t st, const Level& L, long long n, const unsi
     // (with a device-side count `n` is the queue's capacity: deep levels then take the large tiles too — measured in graph
     // mode, 20-27 us per launch against 24-36 us with small tiles, whose many empty workgroups cost more than they spread)
     if (n > 1500000) {
-        constexpr long long T = (long long)TILE_ITERS * BLOCK;
-        hipLaunchKernelGGL(k_queue<TILE_ITERS>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
+        constexpr long long T = (long long)TILE_ITERS * QBLOCK;
+        hipLaunchKernelGGL(k_queue<TILE_ITERS>, dim3(unsigned((n + T - 1) / T)), dim3(QBLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
     } else {
-        constexpr long long T = (long long)TILE_ITERS_SMALL * BLOCK;
-        hipLaunchKernelGGL(k_queue<TILE_ITERS_SMALL>, dim3(unsigned((n + T - 1) / T)), dim3(BLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
+        constexpr long long T = (long long)TILE_ITERS_SMALL * QBLOCK;
+        hipLaunchKernelGGL(k_queue<TILE_ITERS_SMALL>, dim3(unsigned((n + T - 1) / T)), dim3(QBLOCK), 0, st, L, n, n_dev, next_cap, ctr, next_tag);
     }
 }
 

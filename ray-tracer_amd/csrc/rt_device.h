@@ -114,20 +114,23 @@ struct Level {
 // Device counters (one int64 each).  A frame uses one block of CNT_TOTAL counters per recursion level (plus one for
 // the launch after the last level), all zeroed when the frame starts.
 enum Counter : int {
-    CNT_REFLECT = 0,   // reflection rays spawned
+    // the three words k_queue reserves queue slots from, one returning atomic per tile each: every one on a cache line
+    // (16 counters) of its own — returning atomics on one line are served one after the other, chip-wide
+    CNT_NEXT = 0,           // rays appended to the next level
+    CNT_SHADOW_Q = 16,      // entries of the level's shadow queue (= nodes that hit something)
+    CNT_CONTAINER_Q = 32,   // entries of the level's container queue (n1/n2 walks)
+    // plain tallies (non-returning adds)
+    CNT_REFLECT = 48,  // reflection rays spawned
     CNT_REFRACT,       // refraction rays spawned
     CNT_TIR,           // refraction slots reserved by k_queue that total internal reflection left dead
-    CNT_NEXT,          // rays appended to the next level
-    CNT_SHADOW_Q,      // entries of the level's shadow queue (= nodes that hit something)
-    CNT_CONTAINER_Q,   // entries of the level's container queue (n1/n2 walks)
     CNT_OVERFLOW,      // block 0 only: level-0 rays whose tree ran into a bounded list (RT_FLAG_LIST_OVERFLOW)
     // work of the instrumented build (rt_render_opts.want_counters), RT_WORK_COUNT rows per kernel class
-    CNT_W_XFORMS,                                    // closest-hit part of k_trace for this level's rays
+    CNT_W_XFORMS = 64,                               // closest-hit part of k_trace for this level's rays
     CNT_WS_XFORMS = CNT_W_XFORMS + RT_WORK_COUNT,    // shadow rays of THIS level's hits (traced by the next k_trace)
     CNT_WC_XFORMS = CNT_WS_XFORMS + RT_WORK_COUNT,   // k_walk
     CNT_COUNT = CNT_WC_XFORMS + RT_WORK_COUNT,       // what the host reads back
     // chunk feeds of the persistent traversal kernels: FEED_PARTS counters per kernel, FEED_STRIDE apart
-    CNT_FEED_TRACE = 64,
+    CNT_FEED_TRACE = 112,
     CNT_FEED_SHADOW = CNT_FEED_TRACE + FEED_PARTS * FEED_STRIDE,
     CNT_FEED_CONTAINER = CNT_FEED_SHADOW + FEED_PARTS * FEED_STRIDE,
     CNT_TOTAL = CNT_FEED_CONTAINER + FEED_PARTS * FEED_STRIDE

@@ -1639,19 +1639,20 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
 // Queue appends without an atomic per wavefront (returning atomics on one word are serialised in L2, 5-10 ns each
 // chip-wide): a workgroup owns a TILE of consecutive rays, counts its appends in a first pass over the stage bits,
 // reserves its slots with ONE atomic per queue, then writes the entries in a second pass with slots known.
-// A tile is ITERS x BLOCK rays: 8192 for large levels (few atomics), 2048 for small ones (a level of 300k rays would
+// A tile is ITERS x QBLOCK rays: 8192 for large levels (few atomics), 2048 for small ones (a level of 300k rays would
 // otherwise occupy 37 of the 256 compute units and take as long as one of 2M).
-constexpr int TILE_ITERS = 32;
-constexpr int TILE_ITERS_SMALL = 8;
+constexpr int QBLOCK = 1024;  // 16 wavefronts share a tile: 8 (2) rays per lane, short dependent chains
+constexpr int TILE_ITERS = 8;
+constexpr int TILE_ITERS_SMALL = 2;
 struct TileSlots {
-    int off[4][TILE_ITERS][BLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
+    int off[4][TILE_ITERS][QBLOCK / 64];  // pass 1: counts; after the scan: offsets inside the reservation
     long long base[3];                   // shadow queue, container queue, next level
 };
 
 template <int ITERS>
-__global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const unsigned long long* n_dev, long long next_cap,
+__global__ __launch_bounds__(QBLOCK) void k_queue(Level L, long long n_cap, const unsigned long long* n_dev, long long next_cap,
                                                  unsigned long long* counters, int32_t* __restrict__ next_tag) {
-    constexpr int TILE = ITERS * BLOCK;
+    constexpr int TILE = ITERS * QBLOCK;
     const long long n = level_count(n_cap, n_dev);
     if ((long long)blockIdx.x * TILE >= n) return;  // whole workgroup beyond the level
     __shared__ TileSlots ts;
@@ -1660,12 +1661,12 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
     if (ITERS < TILE_ITERS) {  // the scan below runs over all TILE_ITERS x 4 counts: the unused ones are zero
         int* flat = &ts.off[0][0][0];
         for (int q = 0; q < 4; ++q)
-            for (int k = ITERS * (BLOCK / 64) + threadIdx.x; k < TILE_ITERS * (BLOCK / 64); k += BLOCK) flat[q * TILE_ITERS * (BLOCK / 64) + k] = 0;
+            for (int k = ITERS * (QBLOCK / 64) + threadIdx.x; k < TILE_ITERS * (QBLOCK / 64); k += QBLOCK) flat[q * TILE_ITERS * (QBLOCK / 64) + k] = 0;
     }
     int stage[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {  // independent coalesced loads, all in flight together
-        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        long long i = tile0 + (long long)it * QBLOCK + threadIdx.x;
         stage[it] = i < n ? L.mode[i] : 0;
     }
 #pragma unroll
@@ -1681,7 +1682,7 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
     // exclusive scans of the per-(iteration, wavefront) counts, one wavefront per queue (a single thread walking the
     // 128 entries through LDS cost ~10 us per tile): lane l owns entries 2l and 2l+1
     {
-        constexpr int PER = TILE_ITERS * (BLOCK / 64) / 64;  // entries per lane
+        constexpr int PER = TILE_ITERS * (QBLOCK / 64) / 64;  // entries per lane
         static_assert(PER == 2, "k_queue's scan assumes 128 entries per queue");
         int* flat0 = &ts.off[0][0][0];
         auto wave_exclusive = [&](int v) {  // exclusive prefix sum over the wavefront; returns (prefix, total via reference)
@@ -1690,15 +1691,15 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
             return inc - v;
         };
         if (wave < 2) {  // shadow queue, container queue
-            int* f = flat0 + wave * TILE_ITERS * (BLOCK / 64);
+            int* f = flat0 + wave * TILE_ITERS * (QBLOCK / 64);
             const int c0 = f[2 * lane], c1 = f[2 * lane + 1];
             const int pre = wave_exclusive(c0 + c1);
             f[2 * lane] = pre; f[2 * lane + 1] = pre + c0;
             const int total = __shfl(pre + c0 + c1, 63, 64);
             if (lane == 0) ts.base[wave] = total ? (long long)atomicAdd(counters + (wave == 0 ? CNT_SHADOW_Q : CNT_CONTAINER_Q), (unsigned long long)total) : 0;
         } else if (wave == 2) {  // both ray kinds share the next level's queue: reflection rays of a wavefront first
-            int* f2 = flat0 + 2 * TILE_ITERS * (BLOCK / 64);
-            int* f3 = flat0 + 3 * TILE_ITERS * (BLOCK / 64);
+            int* f2 = flat0 + 2 * TILE_ITERS * (QBLOCK / 64);
+            int* f3 = flat0 + 3 * TILE_ITERS * (QBLOCK / 64);
             const int a0 = f2[2 * lane], b0 = f3[2 * lane], a1 = f2[2 * lane + 1], b1 = f3[2 * lane + 1];
             const int pre = wave_exclusive(a0 + b0 + a1 + b1);
             f2[2 * lane] = pre; f3[2 * lane] = pre + a0; f2[2 * lane + 1] = pre + a0 + b0; f3[2 * lane + 1] = pre + a0 + b0 + a1;
@@ -1715,7 +1716,7 @@ __global__ __launch_bounds__(BLOCK) void k_queue(Level L, long long n_cap, const
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        long long i = tile0 + (long long)it * BLOCK + threadIdx.x;
+        long long i = tile0 + (long long)it * QBLOCK + threadIdx.x;
         const int st = stage[it];
         unsigned long long b0 = __ballot(st & ST_HIT), b1 = __ballot(st & ST_WALK);
         unsigned long long b2 = __ballot(st & ST_REFLECT), b3 = __ballot(st & ST_REFRACT);
