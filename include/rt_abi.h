@@ -230,7 +230,7 @@ typedef struct rt_stats {
                           plus one for the shadow rays of the last level                                                */
     double ms_shadow;  /* always 0: the shadow rays have no launch of their own (kept for ABI stability)                */
     double ms_collect; /* k_walk launches: the n1/n2 container walks                                                    */
-    double ms_shade;   /* k_queue + k_spawn (queue compaction, reflection / refraction ray spawn)                       */
+    double ms_shade;   /* k_queue (queue compaction; + k_spawn when rt_scene_opts.fuse_spawn is 0)                      */
     double ms_resolve; /* k_shade: lighting + schlick + bottom-up blend                                                 */
     int32_t n_trace_launches;  /* k_trace launches                                                                      */
     int32_t n_shadow_launches; /* k_walk launches                                                                       */
