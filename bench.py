@@ -93,6 +93,11 @@ def cpu_baseline_all_cores(args):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: libraries that print there (RCCL's version banner at communicator
+    # creation, for one) are sent to stderr by pointing file descriptor 1 at it for the rest of the run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # 0.33 s of frames: long enough for the driver's GPU-activity sampler
@@ -378,7 +383,7 @@ def main():
                            % (args.height * args.width * 24 / 1e6)},
                "c5_grid4_8k": c5, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
                "cpu_baseline": cpu}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

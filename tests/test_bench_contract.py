@@ -28,3 +28,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None  # no PMC passes exist for this frame size: null, not the headline's figure
+
+
+@pytest.mark.gpu
+def test_sharded_bench_path_prints_one_json_line_too():
+    """The multi-rank code path (RCCL gather + rt_assemble), rehearsed with one rank: RCCL prints a version banner on
+    stdout when its communicator is created, and stdout must still carry the JSON line alone."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-sharded", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-c5", "--width", "480", "--height", "270"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
