@@ -41,6 +41,7 @@ B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle t
 B_RAY_IO = {"k_trace": 48 + 17, "k_trace_spawned": 4 + 76 + 17, "k_trace_hit": 56, "k_trace_spawned_hit": 48, "shadow": 4 + 48 + 1,
             "container": 4 + 64 + 16 + 4, "k_queue": 4 + 8 + 8, "k_shade": 4 + 4 + 72 + 16 + 1 + 24 + 24}
 
+FP64_FMA_SPEC_TFLOPS = 78.6   # AMD's FP64 vector figure for MI355X: counts an FMA as two operations
 FP64_VALU_PEAK_TFLOPS = 39.3  # MI355X FP64 vector: 78.6 TFLOP/s counting FMA as 2 (AMD spec); with -ffp-contract=off
                               # (mandatory for reference parity) every op is a separate mul/add => half of that
 FP64_VALU_MEASURED_TFLOPS = 35.6  # scripts/fp64_roof.hip on the box (profiles/fp64_roof.json): v_mul_f64 + v_add_f64 chains, 8 waves/SIMD
@@ -110,7 +111,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="N = 1 only: take the N > 1 code path (rt_render_shard, RCCL gather in a one-rank group, rt_assemble_strided)")
-    ap.add_argument("--no-c5", action="store_true", help="skip the second workload (C5 grid 4 at 8K) reported for the scaling sweep")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 workloads (grid 4 and grid 13 at 8K) reported beside the headline")
+    ap.add_argument("--gather", default="f64", choices=["f64", "u8"],
+                    help="sharded path: what travels over xGMI. f64: the f64 RGB shards (24 B/px); u8: scale_color on each rank's "
+                         "shard first (rt_quantise), 3 B/px, the root assembles the u8 frame canvas_to_ppm reads")
     ap.add_argument("--cpu-stride", type=int, default=12)
     args = ap.parse_args()
 
@@ -163,11 +167,19 @@ def main():
         # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
         gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and sharded) else None
         gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
+        u8 = sharded and args.gather == "u8"
+        if u8:   # scale_color per rank before the gather (src/canvas.rs:86-98): 8x fewer bytes over xGMI; the root keeps a u8 frame
+            shards_q = [torch.zeros((n_max, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+            gathered_all = torch.zeros((world, n_max, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+            gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
+            frame = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
         opts = rt.RenderOpts(max_depth=depth, rank=rank, n_ranks=world, want_counters=0, stream=None)
         torch_stream = torch.cuda.current_stream(dev).cuda_stream if sharded else None
         state = {"k": 0}
 
-        def step(stats=None):
+        def step(stats=None, phases=None):
+            """phases: a dict that receives this step's shard_ms (host clock around rt_render_shard, which returns when the
+            shard is complete in HBM), gather_ms and assemble_ms (events on torch's stream, the one those two are enqueued on)"""
             if not sharded:
                 # one GPU: Camera::render straight into the row-major frame in HBM (rt_render_frame), one blocking call
                 rc = rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None,
@@ -180,21 +192,63 @@ def main():
             if gather_done[b] is not None:
                 gather_done[b].synchronize()          # the gather that read this buffer two frames ago
             # returns when the shard is complete in HBM (the library waits once per frame for its ray counters)
+            t_host = time.perf_counter()
             rc = rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None,
                                         C.byref(stats) if stats is not None else None)
             if rc < 0:
                 raise RuntimeError(rt.last_error())
-            dist.gather(shards[b], gathered, dst=0)   # RCCL gather over xGMI: no reduction, peers -> root; enqueued, not waited for
-            if rank == 0:                             # stream-ordered behind the gather on torch's stream
-                rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None,
-                                                C.c_void_p(torch_stream))
+            t_host = time.perf_counter() - t_host
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if phases is not None else None
+            if e:
+                e[0].record()
+            send = shards[b]
+            if u8:   # on torch's stream, like the gather behind it
+                rc = rt.lib.rt_quantise(scene, shards[b].data_ptr(), n_max * 3, shards_q[b].data_ptr(), C.c_void_p(torch_stream))
                 if rc < 0:
                     raise RuntimeError(rt.last_error())
-            ev = torch.cuda.Event()
+                send = shards_q[b]
+            dist.gather(send, gathered, dst=0)        # RCCL gather over xGMI: no reduction, peers -> root; enqueued, not waited for
+            if e:
+                e[1].record()
+            if rank == 0:                             # stream-ordered behind the gather on torch's stream
+                if u8:
+                    rc = rt.lib.rt_assemble_quantised(scene, C.byref(cd), world, gathered_all.data_ptr(), n_max, frame.data_ptr(),
+                                                      C.c_void_p(torch_stream))
+                else:
+                    rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None,
+                                                    C.c_void_p(torch_stream))
+                if rc < 0:
+                    raise RuntimeError(rt.last_error())
+            ev = torch.cuda.Event(enable_timing=phases is not None)
             ev.record()
             gather_done[b] = ev
+            if e:
+                ev.synchronize()
+                phases["shard_ms"] = phases.get("shard_ms", 0.) + t_host * 1e3
+                phases["gather_ms"] = phases.get("gather_ms", 0.) + e[0].elapsed_time(e[1])
+                phases["assemble_ms"] = phases.get("assemble_ms", 0.) + e[1].elapsed_time(ev)
+                phases["frames"] = phases.get("frames", 0) + 1
 
-        return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, gathered_all)}
+        return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, gathered_all), "frame": frame}
+
+    def sharded_report(step, frames=5):
+        """Per-rank phase times of the sharded path, a few untimed frames each waited for: what the first real N > 1 run needs
+        to explain itself (is it the shard render's launch floor, the gather, or the scatter?)."""
+        if not sharded:
+            return None
+        ph = {}
+        for _ in range(frames):
+            step(None, ph)
+        mine = torch.tensor([ph["shard_ms"] / frames, ph["gather_ms"] / frames, ph["assemble_ms"] / frames], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "gather": args.gather,
+                "bytes_per_pixel_on_the_wire": 3 if args.gather == "u8" else 24,
+                "per_rank": [{"rank": r, "shard_ms": round(float(t[0]), 4), "gather_ms": round(float(t[1]), 4),
+                              "assemble_ms": round(float(t[2]), 4)} for r, t in enumerate(every)],
+                "what": "means over %d untimed frames, each waited for: shard_ms = host clock around rt_render_shard (returns when the "
+                        "shard is in HBM), gather_ms / assemble_ms = events on the stream the gather and the scatter are enqueued on "
+                        "(assemble runs on rank 0 only)" % frames}
 
     def timed(step, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks, in ms per step."""
@@ -231,8 +285,8 @@ def main():
 
     # ---- SURVEY 8(d)'s literal metric, reported next to `value`: rt_render = the same frame with HOST output buffers
     # (one 49.8 MB D2H copy of the f64 frame at 1080p included).  Never `value`: that is the HBM-resident rate.
-    host_ms = host_ms_pageable = None
-    if world == 1:
+    host_ms = host_ms_pageable = host_ms_pipelined = None
+    if world == 1 and not sharded:
         def time_rt_render(host_rgb):
             for _ in range(2):
                 rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), host_rgb.ctypes.data_as(rt.c_dp), None, None, None)
@@ -246,10 +300,30 @@ def main():
         host_ms = time_rt_render(rt.pinned_array((args.height, args.width, 3)))      # buffer from rt_host_alloc
         host_ms_pageable = time_rt_render(np.zeros((args.height, args.width, 3)))     # any malloc'ed buffer
 
+        def time_rt_render_pipelined():
+            """rt_render_begin / rt_render_end: the same frames into two page-locked host buffers used in turn, the D2H copy of
+            frame k on a copy stream while frame k + 1 is rendered; every frame is complete in host memory when its end returns"""
+            bufs = [rt.pinned_array((args.height, args.width, 3)) for _ in range(2)]
+            def run(n):
+                for k in range(n):
+                    rc = rt.lib.rt_render_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1].ctypes.data_as(rt.c_dp), None, None)
+                    if rc < 0:
+                        raise RuntimeError(rt.last_error())
+                    if k >= 1 and rt.lib.rt_render_end(scene) < 0:
+                        raise RuntimeError(rt.last_error())
+                if rt.lib.rt_render_end(scene) < 0:
+                    raise RuntimeError(rt.last_error())
+            run(4)
+            n_host = max(6, min(args.steps, 40))
+            t0 = time.perf_counter()
+            run(n_host)
+            return (time.perf_counter() - t0) / n_host * 1e3
+        host_ms_pipelined = time_rt_render_pipelined()
+
     # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
     st, rays = ray_counts(step)
     n_ev = 5
-    ev = {"ms_trace": 0.0, "ms_collect": 0.0, "ms_shade": 0.0, "ms_resolve": 0.0, "ms_total": 0.0}
+    ev = {"ms_trace": 0.0, "ms_walk": 0.0, "ms_queue": 0.0, "ms_kshade": 0.0, "ms_total": 0.0}
     for _ in range(n_ev):
         s2 = rt.Stats()
         step(s2)
@@ -260,22 +334,31 @@ def main():
     step(sc)
     opts.want_counters = 0
     total_rays = sum(rays[:4])
+    sharded_info = sharded_report(step)
 
     # ---- second workload, for the scaling sweep (the driver runs this file at N = 1, 2, 4, 8 with default arguments):
     # a 1.8 ms frame cannot scale across GPUs (launch floors and the gather dominate), C5 can.  Reported beside the
     # headline, never as `value`: 4 x 4 instanced teapots (101,120 triangles), 7680x4320, depth 8, same tile sharding.
-    c5 = None
+    c5 = c5_13 = None
     if args.scene == "teapot" and not args.no_c5:
         barrier()
         del job, step
-        w5, cam5 = scenes.instanced_grid(7680, 4320, grid=4)
-        job5 = make_job(w5, cam5, 8, 7680, 4320)
-        ms5 = timed(job5["step"], 20, 3)
-        _, rays5 = ray_counts(job5["step"])
-        c5 = {"workload": "configs[4] geometry at grid 4: 16 instanced teapots (101,120 triangles) + floor, 7680x4320, depth 8",
-              "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-              "steps": 20, "warmup": 3, "rays_per_frame": sum(rays5[:4]), "n_gpus": world}
-        del job5
+
+        def run_c5(grid, what):
+            w5, cam5 = scenes.instanced_grid(7680, 4320, grid=grid)
+            job5 = make_job(w5, cam5, 8, 7680, 4320)
+            ms5 = timed(job5["step"], 20, 3)
+            _, rays5 = ray_counts(job5["step"])
+            out5 = {"workload": what, "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                    "steps": 20, "warmup": 3, "rays_per_frame": sum(rays5[:4]), "n_gpus": world,
+                    "sharded": sharded_report(job5["step"], 3)}
+            w5.invalidate()
+            del job5
+            return out5
+        c5 = run_c5(4, "configs[4] geometry at grid 4: 16 instanced teapots (101,120 triangles) + floor, 7680x4320, depth 8")
+        # the survey's scale (1-4 M triangles): 13 x 13 teapots + 13 x 13 triangles.obj = 1,068,418 triangles
+        c5_13 = run_c5(13, "configs[4] at the survey's scale, grid 13: 169 instanced teapots + 169 triangles.obj (1,068,418 triangles) "
+                           "+ floor, 7680x4320, depth 8")
 
     if rank == 0:
         n_lights = len(w.lights)
@@ -284,9 +367,9 @@ def main():
         # the three kinds of work apart (work_trace / work_shadow / work_container).
         w_tr = [a + b for a, b in zip(sc.work_trace, sc.work_shadow)]
         works = {"k_trace": w_tr, "k_walk": list(sc.work_container)}
-        ms = {"k_trace": ev["ms_trace"], "k_walk": ev["ms_collect"], "k_queue": ev["ms_shade"], "k_shade": ev["ms_resolve"]}
-        launches = {"k_trace": st.n_trace_launches, "k_walk": st.n_shadow_launches,
-                    "k_queue": st.n_trace_launches - 1, "k_shade": st.n_trace_launches - 1}
+        ms = {"k_trace": ev["ms_trace"], "k_walk": ev["ms_walk"], "k_queue": ev["ms_queue"], "k_shade": ev["ms_kshade"]}
+        launches = {"k_trace": st.n_trace_launches, "k_walk": st.n_walk_launches,
+                    "k_queue": max(st.n_trace_launches - 1, 1), "k_shade": max(st.n_trace_launches - 1, 1)}
         spawned = st.rays_reflect + st.rays_refract
         traced = st.rays_primary + spawned
         flops = {k: work_flops(v) for k, v in works.items()}
@@ -319,6 +402,7 @@ def main():
         achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         roofline = {"kernel": dom, "bound": "fp64_valu", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
+                    "frac_vs_fma_spec": round(achieved / FP64_FMA_SPEC_TFLOPS, 5),
                     "peak_measured": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured": round(achieved / FP64_VALU_MEASURED_TFLOPS, 5),
                     "launches_per_frame": n_launch, "avg_launch_ms": round(ms[dom] / n_launch, 5),
                     "source": "HIP events on the launch stream around every launch of %d rt_stats frames; those frames run "
@@ -331,9 +415,18 @@ def main():
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
                             "reference parity forbids FMA contraction"}
-        hbm_ach = nbytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
-        roofline_hbm = {"kernel": dom, "bound": "hbm", "achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(hbm_ach / HBM_PEAK_GBS, 5), "traffic": pmc}
+        # The HBM leg is priced on MEASURED traffic (PMC passes), never on algorithmic bytes: those count 128 B per BVH node
+        # even when the node comes out of LDS and 80 B per triangle even when L2 serves it, so bytes / time can exceed what
+        # HBM delivers.  No PMC file for this workload: null.
+        launch_s = ms[dom] * 1e-3 / n_launch if ms[dom] > 0 else 0.0
+        hbm_ach = pmc / launch_s / 1e9 if (pmc is not None and launch_s > 0) else None
+        roofline_hbm = {"kernel": dom, "bound": "hbm", "achieved": None if hbm_ach is None else round(hbm_ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": None if hbm_ach is None else round(min(hbm_ach / HBM_PEAK_GBS, 1.0), 5), "traffic": pmc,
+                        "traffic_source": roofline["traffic_source"],
+                        "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
+                        "algorithmic_GBps": round(nbytes[dom] / (ms[dom] * 1e-3) / 1e9, 2) if ms[dom] > 0 else None,
+                        "note": "achieved = measured HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE passes) / average launch "
+                                "duration; algorithmic_* = SURVEY 8(d) bytes, served largely by LDS and L2, reported apart"}
         kernels = {k: {"ms_per_frame": round(ms[k], 4), "launches_per_frame": launches[k], "algorithmic_flops": int(flops[k]),
                        "algorithmic_bytes": int(nbytes[k]),
                        "tflops": round(flops[k] / (ms[k] * 1e-3) / 1e12, 4) if ms[k] > 0 else None} for k in ms}
@@ -375,13 +468,17 @@ def main():
                "value_is": "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), scene resident before the "
                            "timed region",
                "rt_render_host": None if host_ms is None else {
-                   "ms_per_frame": round(host_ms, 4), "Mrays_s": round(total_rays / (host_ms * 1e-3) / 1e6, 3),
+                   "ms_per_frame": round(host_ms_pipelined, 4), "Mrays_s": round(total_rays / (host_ms_pipelined * 1e-3) / 1e6, 3),
+                   "ms_per_frame_blocking_rt_render": round(host_ms, 4),
                    "ms_per_frame_pageable_buffer": round(host_ms_pageable, 4),
-                   "what": "rt_render: the same frame into a HOST f64 buffer, D2H copy of %.1f MB included (SURVEY 8(d)'s "
-                           "wording of the metric; PCIe-inclusive, so never `value`); the buffer comes from rt_host_alloc "
-                           "(page-locked), the second figure is the same call into pageable memory"
+                   "what": "SURVEY 8(d)'s wording of the metric — every frame complete in a HOST f64 buffer, the D2H copy of %.1f MB "
+                           "included; PCIe-inclusive, so never `value`.  ms_per_frame: rt_render_begin / rt_render_end, frame "
+                           "after frame into two page-locked buffers (rt_host_alloc) used in turn, the copy of frame k on a copy "
+                           "stream beside the render of frame k + 1; ms_per_frame_blocking_rt_render: one rt_render call per frame "
+                           "(render, then copy) into a page-locked buffer; the last figure: rt_render into pageable memory"
                            % (args.height * args.width * 24 / 1e6)},
-               "c5_grid4_8k": c5, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
+               "sharded": sharded_info,
+               "c5_grid4_8k": c5, "c5_grid13_8k": c5_13, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "reference_algorithm": reference_work,
                "cpu_baseline": cpu}
         print(json.dumps(out), file=json_out, flush=True)
     if sharded:

@@ -223,17 +223,20 @@ typedef struct rt_stats {
     int32_t levels;         /* recursion levels that held at least one ray                            */
     int32_t _pad;
     /* device time per kernel class, ms, measured with HIP events on the launch stream around every launch of the SAME
-     * schedule the untimed calls run (no host wait between launches; the events are read after the frame) */
+     * schedule the untimed calls run (no host wait between launches; the events are read after the frame).
+     * Field names say which kernel they time (round 3 renamed them: the layout is round 2's, where the same slots were
+     * called ms_collect / ms_shade / ms_resolve / n_shadow_launches after kernels that no longer exist — a reader of
+     * the old names fails to compile instead of silently misattributing time). */
     double ms_total;
     double ms_raygen;
     double ms_trace;   /* k_trace launches: closest hits of level d + the shadow rays of level d-1, one launch per level,
                           plus one for the shadow rays of the last level                                                */
-    double ms_shadow;  /* always 0: the shadow rays have no launch of their own (kept for ABI stability)                */
-    double ms_collect; /* k_walk launches: the n1/n2 container walks                                                    */
-    double ms_shade;   /* k_queue (queue compaction; + k_spawn when rt_scene_opts.fuse_spawn is 0)                      */
-    double ms_resolve; /* k_shade: lighting + schlick + bottom-up blend                                                 */
-    int32_t n_trace_launches;  /* k_trace launches                                                                      */
-    int32_t n_shadow_launches; /* k_walk launches                                                                       */
+    double ms_shadow;  /* always 0: the shadow rays have no launch of their own (slot kept for layout stability)        */
+    double ms_walk;    /* k_walk launches: the n1/n2 container walks                                                    */
+    double ms_queue;   /* k_queue (queue compaction; + k_spawn when rt_scene_opts.fuse_spawn is 0)                      */
+    double ms_kshade;  /* k_shade: lighting + schlick + bottom-up blend                                                 */
+    int32_t n_trace_launches; /* k_trace launches                                                                       */
+    int32_t n_walk_launches;  /* k_walk launches                                                                        */
     /* algorithmic work counted by the instrumented kernels (want_counters = 1), per kernel class; the
      * RT_WORK_* indices name the rows, SURVEY.md section 8(d) constants turn them into flops / bytes */
     int64_t work_trace[RT_WORK_COUNT];     /* closest-hit part of k_trace         */
@@ -299,6 +302,20 @@ void rt_scene_destroy(rt_scene* scene);
  *   stats_out   nullable */
 int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
               int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats_out);
+
+/* Camera::render (src/camera.rs:62-74, which RETURNS a host Canvas) for callers that render frame after frame: the
+ * same frame as rt_render into the same HOST buffers, but the device-to-host copy is taken off the critical path.
+ * rt_render_begin renders the frame (whole frames only: opts->rank 0 of 1, opts->stream ignored) into one of two
+ * device frames the scene uses in turn, enqueues the copies to rgb_out / hit_id_out / flags_out (the last two nullable)
+ * on a copy stream of its own and returns; the buffers hold the frame once the matching rt_render_end has returned.
+ * At most two frames may be in flight; rt_render_end retires the oldest one (and returns RT_OK at once when none is).
+ *     begin(A); begin(B); end() -> A complete; begin(A'); end() -> B complete; ...
+ * so the 0.85 ms copy of a 1920x1080 f64 frame overlaps the next frame's render: 1.7 instead of 2.5 ms per frame at the
+ * host (buffers from rt_host_alloc; a pageable buffer makes the runtime stage the copy and the overlap is lost).  The
+ * caller must not touch a buffer between its begin and the end that retires it.  rt_scene_destroy retires everything. */
+int rt_render_begin(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
+                    int32_t* hit_id_out, uint8_t* flags_out);
+int rt_render_end(rt_scene* scene);
 
 /* Number of pixels shard `rank` of `n_ranks` renders (8x8-pixel tiles of the (hsize-1)x(vsize-1) domain dealt
  * round-robin).  Negative on bad arguments. */
@@ -368,6 +385,17 @@ int rt_assemble(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, 
 int rt_assemble_strided(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const double* d_rgb_shards,
                         const int32_t* d_hit_id_shards, int64_t shard_stride, double* d_rgb_frame,
                         int32_t* d_hit_id_frame, void* stream);
+
+/* Canvas::scale_color (src/canvas.rs:86-98) for n_values f64 channel values in DEVICE memory: clamp to [0, 1], times 255,
+ * f64::round (half away from zero), NaN -> 0.  What a one-process-per-GPU driver runs on its shard before the gather:
+ * 3 bytes per pixel over xGMI instead of 24.  Ordered on `stream` (NULL: the scene's stream, and the call waits). */
+int rt_quantise(rt_scene* scene, const double* d_rgb, int64_t n_values, uint8_t* d_quantised_out, void* stream);
+
+/* rt_assemble_strided for quantised shards (u8 RGB, 3 bytes per pixel; shard r starts at pixel r * shard_stride, 0 = back
+ * to back): the scatter of Canvas::write_pixel's loop (src/camera.rs:65-71) for the u8 frame Canvas::canvas_to_ppm reads
+ * (src/canvas.rs:33-84).  d_q_frame [vsize*hsize*3] device, zero where no shard writes. */
+int rt_assemble_quantised(rt_scene* scene, const rt_camera_desc* camera, int32_t n_ranks, const uint8_t* d_q_shards,
+                          int64_t shard_stride, uint8_t* d_q_frame, void* stream);
 
 /* World::color_at (src/world.rs:81-90) for a batch of arbitrary rays, host buffers.
  *   origins, directions [n_rays][3]; rgb_out [n_rays][3]; hit_id_out / flags_out nullable [n_rays]. */

@@ -102,6 +102,8 @@ struct rt_scene {
     unsigned long long* d_counters = nullptr;
     unsigned long long* h_counters = nullptr;
     int counter_blocks = 0;
+    long long* h_word = nullptr;  // one page-locked int64 made at creation: read-backs of a single device word (the entry
+                                  // point that allocates nothing must not make the runtime stage a pageable copy)
     GrowBuf out_rgb, out_id, out_flags, frame_rgb, frame_id, frame_flags, in_a, in_b, misc_a, misc_b, misc_c;
     std::vector<hipEvent_t> events;  // timing pool of the rt_stats path (events on the launch stream)
     // Overflow fix-up (rays whose tree ran into a bounded per-lane list are traced again by the BIG kernel variants):
@@ -117,9 +119,18 @@ struct rt_scene {
     // The enqueue of a whole frame (~35 launches) is captured once into a HIP graph and replayed with one call while
     // everything it bakes in stays the same (camera, shard, depth, output pointers, queue blocks): `graph_key` is the
     // byte image of those.
-    hipGraphExec_t graph_exec = nullptr;
-    std::string graph_key;
+    // A few instantiated graphs are kept (least recently used goes first): callers that alternate between two output
+    // buffers — rt_render_begin's two device frames, a one-process-per-GPU driver's two shard buffers — replay, not recapture.
+    struct GraphEntry { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0;
     bool use_graph = true;
+    // rt_render_begin / rt_render_end: two device frames used in turn, the D2H copy of one on `copy_stream` while the
+    // next is rendered on `stream`
+    hipStream_t copy_stream = nullptr;
+    GrowBuf pipe_rgb[2], pipe_id[2], pipe_flags[2];
+    hipEvent_t pipe_rendered[2] = {nullptr, nullptr}, pipe_copied[2] = {nullptr, nullptr};
+    int pipe_head = 0, pipe_pending = 0;
     bool fuse_output = true;   // graph path: level 0's k_shade writes the shard / frame (RT_AMD_FUSE_OUTPUT=0: A/B)
     bool fuse_spawn = true;    // k_trace makes the rays of levels 1.. as it fetches them (RT_AMD_FUSE_SPAWN=0: k_spawn launches, A/B)
     bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
@@ -407,18 +418,18 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper, d > 0 && s->fuse_spawn); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
-        tm.begin(stats ? &stats->ms_shade : nullptr);
+        tm.begin(stats ? &stats->ms_queue : nullptr);
         launch_queue(st, L, n_arg, n_dev, next_cap, ctr, N.hkey);
         tm.end();
         if (s->any_transparent && (remaining > 0 || s->ds.walk_at_zero)) {
-            tm.begin(stats ? &stats->ms_collect : nullptr);
+            tm.begin(stats ? &stats->ms_walk : nullptr);
             { int rc = launch_walk<COUNT>(s, st, L, n_arg, ctr); if (rc != RT_OK) return rc; }
             tm.end();
-            if (stats) stats->n_shadow_launches++;
+            if (stats) stats->n_walk_launches++;
         }
         if (remaining > 0 && !s->fuse_spawn) {  // one lane per slot of the next level: at most 2 per ray of this one
             const long long slots = std::min(2 * n_arg, next_cap);
-            tm.begin(stats ? &stats->ms_shade : nullptr);
+            tm.begin(stats ? &stats->ms_queue : nullptr);
             hipLaunchKernelGGL(k_spawn, dim3(blocks_for(slots)), dim3(BLOCK), 0, st, L, N, slots, ctr + CNT_NEXT);
             tm.end();
         }
@@ -442,7 +453,7 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         tm.end();
         if (stats) stats->n_trace_launches++;
     }
-    tm.begin(stats ? &stats->ms_resolve : nullptr);
+    tm.begin(stats ? &stats->ms_kshade : nullptr);
     for (int d = last; d >= 0; --d) {
         const Level& L = s->levels[size_t(d)].L;
         const Level& N = d < last ? s->levels[size_t(d) + 1].L : L;
@@ -686,12 +697,27 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     if (!stats && !opts->want_counters && s->use_graph && levels_sized(s, D)) {
         std::string key;
         auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
-        put(cam, sizeof *cam); put(&opts->rank, sizeof opts->rank); put(&opts->n_ranks, sizeof opts->n_ranks);
+        // the camera by its named fields (`c` is derived from exactly those; the struct's padding bytes are not part of
+        // the key: a descriptor rebuilt in uninitialised storage must not force a new capture).  No captured kernel reads
+        // a DScene field that changes after creation (arena*, which only the BIG variants read, and those never run captured).
+        put(c.inv, sizeof c.inv); put(&c.half_width, sizeof(double)); put(&c.half_height, sizeof(double)); put(&c.pixel_size, sizeof(double));
+        put(&c.hsize, sizeof(int32_t)); put(&c.vsize, sizeof(int32_t));
+        put(&opts->rank, sizeof opts->rank); put(&opts->n_ranks, sizeof opts->n_ranks);
         put(&D, sizeof D); put(&d_rgb, sizeof d_rgb); put(&d_id, sizeof d_id); put(&d_flags, sizeof d_flags);
         put(&st, sizeof st); put(&frame, sizeof frame); put(&s->d_counters, sizeof s->d_counters);
         for (int d = 0; d <= D; ++d) { put(&s->levels[size_t(d)].block, sizeof(void*)); put(&s->levels[size_t(d)].cap, sizeof(long long)); }
-        if (!s->graph_exec || key != s->graph_key) {
-            if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+        constexpr size_t GRAPH_SLOTS = 4;
+        hipGraphExec_t graph_exec = nullptr;
+        for (rt_scene::GraphEntry& g : s->graphs)
+            if (g.key == key) { graph_exec = g.exec; g.used = ++s->graph_clock; }
+        if (!graph_exec) {
+            if (s->graphs.size() >= GRAPH_SLOTS) {  // drop the least recently used one
+                size_t lru = 0;
+                for (size_t k = 1; k < s->graphs.size(); ++k)
+                    if (s->graphs[k].used < s->graphs[lru].used) lru = k;
+                (void)hipGraphExecDestroy(s->graphs[lru].exec);
+                s->graphs.erase(s->graphs.begin() + long(lru));
+            }
             hipGraph_t graph = nullptr;
             // a stream that cannot capture (it is being captured by the caller, or capture is unavailable) is not an
             // error: the frame is simply enqueued launch by launch
@@ -707,18 +733,18 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
                     (void)hipGetLastError();
                     s->use_graph = false;
                 } else {
-                    hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+                    hipError_t ei = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
                     (void)hipGraphDestroy(graph);
-                    if (ei != hipSuccess) { s->graph_exec = nullptr; (void)hipGetLastError(); s->use_graph = false; }
-                    else s->graph_key = key;
+                    if (ei != hipSuccess) { graph_exec = nullptr; (void)hipGetLastError(); s->use_graph = false; }
+                    else s->graphs.push_back(rt_scene::GraphEntry{key, graph_exec, ++s->graph_clock});
                 }
             } else {
                 (void)hipGetLastError();
                 s->use_graph = false;
             }
         }
-        if (s->graph_exec) {
-            HIP_TRY(hipGraphLaunch(s->graph_exec, st));
+        if (graph_exec) {
+            HIP_TRY(hipGraphLaunch(graph_exec, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (!levels_overflowed(s, D)) {
                 const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW];
@@ -809,15 +835,34 @@ struct RcclApi {
 };
 constexpr int NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_FLOAT64 = 8;  // ncclDataType_t, rccl.h:459-467
 
+// One entry per value of RT_AMD_RCCL_LIB seen at scene creation ("" = unset): the variable names the one file to try
+// instead of the search below (a host that ships RCCL elsewhere; the tests point it at a file that does not exist to
+// take the "RCCL cannot be loaded" branch).  A multi-GPU scene keeps the entry it was created with (MultiState::rccl).
 static RcclApi& rccl_api() {
-    static RcclApi api = [] {
+    static std::mutex m;
+    static std::map<std::string, std::unique_ptr<RcclApi>> apis;
+    const char* env = std::getenv("RT_AMD_RCCL_LIB");
+    const std::string which = env ? env : "";
+    std::lock_guard<std::mutex> lock(m);
+    std::unique_ptr<RcclApi>& slot = apis[which];
+    if (slot) return *slot;
+    slot.reset(new RcclApi([&which] {
         RcclApi a;
-        const char* names[] = {"librccl.so", "librccl.so.1"};
-        for (const char* n : names)  // a copy the process already holds (PyTorch's bundled one has no soname)
-            if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!a.lib) { a.why = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?"); return a; }
+        const char* only = which.c_str();
+        if (only && *only) {
+            a.lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            const char* names[] = {"librccl.so", "librccl.so.1"};
+            for (const char* n : names)  // a copy the process already holds (PyTorch's bundled one has no soname)
+                if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!a.lib) {
+            const char* e = dlerror();  // ONE call: dlerror() hands the message over and clears it
+            a.why = std::string(only && *only ? only : "librccl.so.1") + " cannot be loaded: " + (e ? e : "?");
+            return a;
+        }
         a.comm_init_all = reinterpret_cast<RcclApi::comm_init_all_t>(dlsym(a.lib, "ncclCommInitAll"));
         a.comm_destroy = reinterpret_cast<RcclApi::comm_destroy_t>(dlsym(a.lib, "ncclCommDestroy"));
         a.group_start = reinterpret_cast<RcclApi::group_t>(dlsym(a.lib, "ncclGroupStart"));
@@ -829,8 +874,8 @@ static RcclApi& rccl_api() {
             a.lib = nullptr;
         }
         return a;
-    }();
-    return api;
+    }()));
+    return *slot;
 }
 
 // A host thread bound to one replica: runs one job at a time, the caller waits for it.
@@ -893,6 +938,7 @@ struct MultiState {
     std::vector<GrowBuf> shard_q;     // per replica: quantised shard (u8 gather)
     GrowBuf g_rgb, g_q, g_id, g_flags, frame_q;  // on the root: gathered shards, u8 frame
     int gather_kind = 0;              // 0: one device, nothing to gather; 1: ncclGather; 2: hipMemcpyPeerAsync
+    RcclApi* rccl = nullptr;          // gather_kind == 1: the library the communicators came from
     std::string gather_note;
 };
 
@@ -1130,6 +1176,10 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         return fail(RT_ERR_HIP);
     }
     if (ensure_counters(s, 16) != RT_OK) return fail(RT_ERR_HIP);
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_word), sizeof(long long), hipHostMallocDefault) != hipSuccess) {
+        rt_set_error("could not allocate the scene's page-locked read-back word");
+        return fail(RT_ERR_HIP);
+    }
     s->use_graph = knobs.graph;
     s->fuse_output = knobs.fuse_output;
     s->fuse_spawn = knobs.fuse_spawn;
@@ -1157,7 +1207,7 @@ void rt_scene_destroy(rt_scene* s) {
         ms->workers.clear();  // joins the threads
         if (ms->gather_kind == 1)
             for (void* c : ms->comms)
-                if (c) (void)rccl_api().comm_destroy(c);
+                if (c && ms->rccl) (void)ms->rccl->comm_destroy(c);
         for (size_t r = 0; r < ms->replicas.size(); ++r) {
             (void)hipSetDevice(ms->devices[r]);
             if (r < ms->sent.size() && ms->sent[r]) (void)hipEventDestroy(ms->sent[r]);
@@ -1174,7 +1224,15 @@ void rt_scene_destroy(rt_scene* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     for (LevelStore& l : s->levels)
         if (l.block) (void)hipFree(l.block);
-    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    for (rt_scene::GraphEntry& g : s->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (int k = 0; k < 2; ++k) {
+        if (s->pipe_copied[k]) { (void)hipEventSynchronize(s->pipe_copied[k]); (void)hipEventDestroy(s->pipe_copied[k]); }
+        if (s->pipe_rendered[k]) (void)hipEventDestroy(s->pipe_rendered[k]);
+        for (GrowBuf* b : {&s->pipe_rgb[k], &s->pipe_id[k], &s->pipe_flags[k]})
+            if (b->p) (void)hipFree(b->p);
+    }
+    if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (LevelStore& l : s->fix_levels)
         if (l.block) (void)hipFree(l.block);
@@ -1187,6 +1245,7 @@ void rt_scene_destroy(rt_scene* s) {
         if (b->p) (void)hipFree(b->p);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
+    if (s->h_word) (void)hipHostFree(s->h_word);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1214,14 +1273,9 @@ int rt_render_shard(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
 int32_t rt_scene_meshes_built_on_gpu(const rt_scene* s) { return s ? s->meshes_built_on_gpu : 0; }
 int32_t rt_scene_meshes_shared(const rt_scene* s) { return s ? s->meshes_shared : 0; }
 
-int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
-                    uint8_t* d_flags_frame, rt_stats* stats) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
-    if (!opts || !d_rgb_frame || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
-    if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
-    hipStream_t st = opts->stream ? static_cast<hipStream_t>(opts->stream) : s->stream;
-    // Canvas::new is all BLACK and Camera::render never writes the last row and column (F1): those are the only
-    // pixels of the frame no shard owns, so they are the only ones cleared here.
+// Canvas::new is all BLACK and Camera::render never writes the last row and column (F1): those are the only pixels of
+// a frame no shard owns, so they are the only ones a whole-frame render has to clear.
+static int clear_frame_border(hipStream_t st, const rt_camera_desc* cam, double* d_rgb_frame, int32_t* d_hit_id_frame, uint8_t* d_flags_frame) {
     const size_t W = size_t(cam->hsize), H = size_t(cam->vsize);
     HIP_TRY(hipMemsetAsync(d_rgb_frame + (H - 1) * W * 3, 0, W * 3 * sizeof(double), st));
     HIP_TRY(hipMemset2DAsync(d_rgb_frame + (W - 1) * 3, W * 3 * sizeof(double), 0, 3 * sizeof(double), H, st));
@@ -1233,6 +1287,16 @@ int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
         HIP_TRY(hipMemsetAsync(d_flags_frame + (H - 1) * W, 0, W, st));
         HIP_TRY(hipMemset2DAsync(d_flags_frame + (W - 1), W, 0, 1, H, st));
     }
+    return RT_OK;
+}
+
+int rt_render_frame(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
+                    uint8_t* d_flags_frame, rt_stats* stats) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !d_rgb_frame || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = opts->stream ? static_cast<hipStream_t>(opts->stream) : s->stream;
+    { int rc0 = clear_frame_border(st, cam, d_rgb_frame, d_hit_id_frame, d_flags_frame); if (rc0 != RT_OK) return rc0; }
     CameraParams c;
     long long n_slots = 0;
     int rc = render_shard_impl(s, cam, opts, st, d_rgb_frame, d_hit_id_frame, d_flags_frame, stats, c, n_slots, true);
@@ -1273,6 +1337,44 @@ int rt_assemble_strided(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks,
     return RT_OK;
 }
 
+// Canvas::scale_color (src/canvas.rs:86-98) for n_values f64 channel values in device memory -> u8, on `stream`.
+int rt_quantise(rt_scene* s, const double* d_rgb, int64_t n_values, uint8_t* d_quantised_out, void* stream) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n_values < 0 || (n_values > 0 && (!d_rgb || !d_quantised_out))) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    if (n_values == 0) return RT_OK;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    hipLaunchKernelGGL(k_quantise, dim3(blocks_for(n_values)), dim3(BLOCK), 0, st, d_rgb, (long long)n_values, d_quantised_out);
+    HIP_TRY(hipGetLastError());
+    if (!stream) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+// rt_assemble_strided for quantised (u8 RGB) shards: what a gather of rt_quantise'd shard buffers leaves on the root.
+int rt_assemble_quantised(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const uint8_t* d_q_shards, int64_t shard_stride,
+                          uint8_t* d_q_frame, void* stream) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!cam || !d_q_shards || !d_q_frame) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    if (shard_stride < 0) { rt_set_error("negative shard stride"); return RT_ERR_BAD_ARG; }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    const size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
+    HIP_TRY(hipMemsetAsync(d_q_frame, 0, npx * 3, st));
+    long long off = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        CameraParams c;
+        long long n_slots = 0, n_valid = 0;
+        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid);
+        if (rc != RT_OK) return rc;
+        if (shard_stride > 0 && n_slots > shard_stride) { rt_set_error("shard %d holds %lld pixels, the stride is %lld", r, n_slots, (long long)shard_stride); return RT_ERR_BAD_ARG; }
+        if (n_slots)
+            hipLaunchKernelGGL(k_assemble_all, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, (const double*)nullptr, d_q_shards + 3 * off,
+                               (const int32_t*)nullptr, (const uint8_t*)nullptr, (double*)nullptr, d_q_frame, (int32_t*)nullptr, (uint8_t*)nullptr);
+        off += shard_stride > 0 ? (long long)shard_stride : n_slots;
+    }
+    HIP_TRY(hipGetLastError());
+    if (!stream) HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
 int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
               uint8_t* flags_out, rt_stats* stats) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
@@ -1285,9 +1387,14 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     if ((rc = grow(s->frame_rgb, npx * 3 * sizeof(double))) != RT_OK) return rc;
     if ((rc = grow(s->frame_id, npx * sizeof(int32_t))) != RT_OK) return rc;
     if ((rc = grow(s->frame_flags, npx)) != RT_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->frame_rgb.p, 0, npx * 3 * sizeof(double), st));  // Canvas::new: all BLACK
-    HIP_TRY(hipMemsetAsync(s->frame_id.p, 0, npx * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(s->frame_flags.p, 0, npx, st));
+    if (opts->n_ranks == 1) {  // every pixel but the F1 border is written by the render itself
+        if ((rc = clear_frame_border(st, cam, static_cast<double*>(s->frame_rgb.p), static_cast<int32_t*>(s->frame_id.p),
+                                     static_cast<uint8_t*>(s->frame_flags.p))) != RT_OK) return rc;
+    } else {
+        HIP_TRY(hipMemsetAsync(s->frame_rgb.p, 0, npx * 3 * sizeof(double), st));  // Canvas::new: all BLACK
+        HIP_TRY(hipMemsetAsync(s->frame_id.p, 0, npx * sizeof(int32_t), st));
+        HIP_TRY(hipMemsetAsync(s->frame_flags.p, 0, npx, st));
+    }
     CameraParams c;
     rc = render_shard_impl(s, cam, opts, st, static_cast<double*>(s->frame_rgb.p), static_cast<int32_t*>(s->frame_id.p),
                            static_cast<uint8_t*>(s->frame_flags.p), stats, c, n_slots, true);  // straight into the frame
@@ -1296,6 +1403,57 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->frame_id.p, npx * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->frame_flags.p, npx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+// Camera::render (src/camera.rs:62-74) with the copy of the Canvas to the host taken off the critical path: the frame is
+// rendered into one of two device frames used in turn, its D2H copy is enqueued on a stream of its own, and the call
+// returns; the copy of frame k then overlaps the render of frame k + 1.  See include/rt_abi.h.
+int rt_render_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
+                    uint8_t* flags_out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!opts || !rgb_out || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
+    if (opts->n_ranks != 1 || opts->rank != 0) { rt_set_error("rt_render_begin renders whole frames (rank 0 of 1)"); return RT_ERR_BAD_ARG; }
+    if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
+    if (s->pipe_pending >= 2) { rt_set_error("two frames are in flight already: call rt_render_end first"); return RT_ERR_BAD_ARG; }
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    const int k = s->pipe_head;
+    if (!s->pipe_rendered[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_rendered[k], hipEventDisableTiming));
+    if (!s->pipe_copied[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_copied[k], hipEventDisableTiming));
+    const size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
+    int rc;
+    if ((rc = grow(s->pipe_rgb[k], npx * 3 * sizeof(double))) != RT_OK) return rc;
+    if (hit_id_out && (rc = grow(s->pipe_id[k], npx * sizeof(int32_t))) != RT_OK) return rc;
+    if (flags_out && (rc = grow(s->pipe_flags[k], npx)) != RT_OK) return rc;
+    double* d_rgb = static_cast<double*>(s->pipe_rgb[k].p);
+    int32_t* d_id = hit_id_out ? static_cast<int32_t*>(s->pipe_id[k].p) : nullptr;
+    uint8_t* d_fl = flags_out ? static_cast<uint8_t*>(s->pipe_flags[k].p) : nullptr;
+    hipStream_t st = s->stream;  // (a caller stream would have to be ordered against the copy stream by the caller)
+    // this device frame's previous copy was waited for by the rt_render_end that retired it (pipe_pending < 2)
+    if ((rc = clear_frame_border(st, cam, d_rgb, d_id, d_fl)) != RT_OK) return rc;
+    rt_render_opts o = *opts;
+    o.stream = nullptr;
+    CameraParams c;
+    long long n_slots = 0;
+    rc = render_shard_impl(s, cam, &o, st, d_rgb, d_id, d_fl, nullptr, c, n_slots, true);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(s->pipe_rendered[k], st));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->pipe_rendered[k], 0));
+    HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, d_id, npx * sizeof(int32_t), hipMemcpyDeviceToHost, s->copy_stream));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, d_fl, npx, hipMemcpyDeviceToHost, s->copy_stream));
+    HIP_TRY(hipEventRecord(s->pipe_copied[k], s->copy_stream));
+    s->pipe_head = k ^ 1;
+    s->pipe_pending++;
+    return RT_OK;
+}
+
+int rt_render_end(rt_scene* s) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (s->pipe_pending == 0) return RT_OK;  // nothing in flight
+    const int k = s->pipe_pending == 2 ? s->pipe_head : s->pipe_head ^ 1;  // the oldest frame begun and not yet retired
+    HIP_TRY(hipEventSynchronize(s->pipe_copied[k]));
+    s->pipe_pending--;
     return RT_OK;
 }
 
@@ -1351,12 +1509,12 @@ int rt_scene_create_opts(const rt_scene_desc* desc, int32_t n_gpus, const int32_
         m->gather_kind = 2;
         if (no_rccl) m->gather_note = "peer copies asked for (rt_scene_opts.gather / RT_AMD_GATHER)";
         else if (!distinct) m->gather_note = "the device list names a device twice (RCCL wants one rank per GPU)";
-        else if (!rccl_api().ok()) m->gather_note = rccl_api().why;
+        else if (RcclApi& R = rccl_api(); !R.ok()) m->gather_note = R.why;
         else {
             m->comms.assign(size_t(n_gpus), nullptr);
-            const int r2 = rccl_api().comm_init_all(m->comms.data(), n_gpus, m->devices.data());
-            if (r2 == 0) { m->gather_kind = 1; m->gather_note = "ncclGather (RCCL)"; }
-            else { m->gather_note = std::string("ncclCommInitAll failed: ") + rccl_api().errstr(r2); m->comms.clear(); (void)hipGetLastError(); }
+            const int r2 = R.comm_init_all(m->comms.data(), n_gpus, m->devices.data());
+            if (r2 == 0) { m->gather_kind = 1; m->rccl = &R; m->gather_note = "ncclGather (RCCL)"; }
+            else { m->gather_note = std::string("ncclCommInitAll failed: ") + R.errstr(r2); m->comms.clear(); (void)hipGetLastError(); }
         }
         if (m->gather_kind == 2) m->gather_note = "hipMemcpyPeerAsync: " + m->gather_note;
     }
@@ -1425,7 +1583,7 @@ int rt_render_multi(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
         return part == 0 ? q->out_rgb.p : part == 1 ? ms->shard_q[size_t(r)].p : part == 2 ? q->out_id.p : q->out_flags.p;
     };
     if (gathered && ms->gather_kind == 1) {
-        RcclApi& R = rccl_api();
+        RcclApi& R = *ms->rccl;
         for (int part = 0; part < 4; ++part) {
             if (!parts[part].on) continue;
             const size_t count = size_t(n_max) * (part == 0 ? 3 : part == 1 ? 3 : 1);  // elements of the part's datatype per rank
@@ -1551,10 +1709,11 @@ int64_t rt_canvas_to_ppm_noalloc(rt_scene* s, const double* d_rgb_frame, int32_t
                            (long long)cap - hl);
     HIP_TRY(hipGetLastError());
     if (d_len_out) return 0;  // the length arrives in *d_len_out in stream order; no host wait here
-    long long body = 0;
-    HIP_TRY(hipMemcpyAsync(&body, rows + vsize, sizeof body, hipMemcpyDeviceToHost, st));
+    // into the page-locked word the scene has held since its creation: a copy into pageable memory is staged by the
+    // runtime through pinned memory it may allocate on first use
+    HIP_TRY(hipMemcpyAsync(s->h_word, rows + vsize, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return hl + body;
+    return hl + *s->h_word;
 }
 
 int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t remaining, double* rgb_out,

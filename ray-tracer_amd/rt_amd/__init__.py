@@ -131,8 +131,8 @@ class Stats(C.Structure):  # rt_stats
                 ("rays_shadow", C.c_int64), ("rays_container", C.c_int64), ("shaded_nodes", C.c_int64),
                 ("levels", C.c_int32), ("_pad", C.c_int32),
                 ("ms_total", C.c_double), ("ms_raygen", C.c_double), ("ms_trace", C.c_double),
-                ("ms_shadow", C.c_double), ("ms_collect", C.c_double), ("ms_shade", C.c_double),
-                ("ms_resolve", C.c_double), ("n_trace_launches", C.c_int32), ("n_shadow_launches", C.c_int32),
+                ("ms_shadow", C.c_double), ("ms_walk", C.c_double), ("ms_queue", C.c_double),
+                ("ms_kshade", C.c_double), ("n_trace_launches", C.c_int32), ("n_walk_launches", C.c_int32),
                 ("work_trace", C.c_int64 * 13), ("work_shadow", C.c_int64 * 13),
                 ("work_container", C.c_int64 * 13)]
 
@@ -158,8 +158,8 @@ class CMaterial(C.Structure):  # rth_material
 
 
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
-ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_shard_pixel_count",
-               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
+ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_begin", "rt_render_end", "rt_shard_pixel_count",
+               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_quantise", "rt_assemble_quantised", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
                "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi", "rt_host_alloc", "rt_host_free",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
@@ -178,6 +178,8 @@ lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_voi
 lib.rt_scene_destroy.argtypes = [C.c_void_p]
 lib.rt_scene_destroy.restype = None
 lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp, C.POINTER(Stats)]
+lib.rt_render_begin.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp]
+lib.rt_render_end.argtypes = [C.c_void_p]
 lib.rt_shard_pixel_count.argtypes = [C.POINTER(CameraDesc), C.c_int32, C.c_int32]
 lib.rt_shard_pixel_count.restype = C.c_int64
 lib.rt_render_shard.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p,
@@ -192,6 +194,8 @@ lib.rt_assemble.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_vo
                             C.c_void_p, C.c_void_p]
 lib.rt_assemble_strided.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
+lib.rt_quantise.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+lib.rt_assemble_quantised.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
 lib.rt_color_at.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, c_ip, c_bp, C.POINTER(Stats)]
 lib.rt_intersect_world.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_ip, c_dp, c_ip]
 lib.rt_is_shadowed.argtypes = [C.c_void_p, C.c_int64, c_dp, c_bp]

@@ -11,6 +11,6 @@ for name, build, size, depth in (("C3", scenes.teapot_scene, (1920, 1080), 5), (
     acc = np.zeros(5)
     for _ in range(8):
         s = cam.render(w, depth).stats
-        acc += [s.ms_trace, s.ms_collect, s.ms_shade, s.ms_resolve, s.ms_total]
+        acc += [s.ms_trace, s.ms_walk, s.ms_queue, s.ms_kshade, s.ms_total]
     acc /= 8
     print(f"{os.environ.get('RT_AMD_LIB', 'in-tree')[-16:]:16s} {name}: k_trace {acc[0]*1e3:7.1f}  k_walk {acc[1]*1e3:6.1f}  k_queue(+k_spawn) {acc[2]*1e3:6.1f}  k_shade {acc[3]*1e3:6.1f}  frame {acc[4]*1e3:7.1f} us", flush=True)

@@ -18,8 +18,8 @@ for depth in range(D + 1):
     acc = None
     for _ in range(R):
         s = cam.render(w, depth).stats
-        row = np.array([s.rays_primary + s.rays_reflect + s.rays_refract, s.shaded_nodes, s.rays_container, s.ms_trace, s.ms_collect,
-                        s.ms_shade, s.ms_resolve, s.ms_total], dtype=float)
+        row = np.array([s.rays_primary + s.rays_reflect + s.rays_refract, s.shaded_nodes, s.rays_container, s.ms_trace, s.ms_walk,
+                        s.ms_queue, s.ms_kshade, s.ms_total], dtype=float)
         acc = row if acc is None else acc + row
     cur = acc / R
     row = cur if prev is None else cur - prev

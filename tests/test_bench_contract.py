@@ -28,6 +28,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None  # no PMC passes exist for this frame size: null, not the headline's figure
+    assert abs(r["frac_vs_fma_spec"] - r["achieved"] / 78.6) < 1e-4
+    h = d["roofline_hbm"]      # the HBM leg is measured traffic / launch time, or null — never algorithmic bytes / time
+    assert h["traffic"] is None and h["achieved"] is None and h["frac"] is None and h["algorithmic_bytes_per_launch"] > 0
+    host = d["rt_render_host"]  # SURVEY 8(d)'s wording: frames complete in host memory; the pipelined pair beside the blocking call
+    assert 0 < host["ms_per_frame"] and 0 < host["ms_per_frame_blocking_rt_render"] <= host["ms_per_frame_pageable_buffer"] * 1.5
+    assert d["sharded"] is None
 
 
 @pytest.mark.gpu
@@ -42,3 +48,22 @@ def test_sharded_bench_path_prints_one_json_line_too():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    sh = d["sharded"]          # the keys the first real N > 1 run explains itself with
+    assert sh["ranks_seen"] == 1 and sh["gather"] == "f64" and sh["bytes_per_pixel_on_the_wire"] == 24 and sh["backend"] == "nccl"
+    assert len(sh["per_rank"]) == 1
+    for k in ("rank", "shard_ms", "gather_ms", "assemble_ms"):
+        assert k in sh["per_rank"][0], k
+    assert sh["per_rank"][0]["shard_ms"] > 0 and sh["per_rank"][0]["gather_ms"] >= 0 and sh["per_rank"][0]["assemble_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_sharded_bench_path_with_the_u8_gather():
+    """--gather u8: scale_color on the shard (rt_quantise), 3 bytes per pixel through the gather, rt_assemble_quantised."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-sharded", "--gather", "u8", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-c5", "--width", "480", "--height", "270"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["sharded"]["gather"] == "u8" and d["sharded"]["bytes_per_pixel_on_the_wire"] == 3 and d["value"] > 0

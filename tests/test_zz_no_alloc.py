@@ -57,6 +57,31 @@ def test_noalloc_ppm_matches_rt_canvas_to_ppm_twice_second_call_smaller():
     _both(w, small, use_len_out=True)
 
 
+def test_noalloc_ppm_leaves_device_memory_where_it_was():
+    """hipMemGetInfo before and after a run of calls (both ways of receiving the length): not a byte of device memory
+    is taken.  The length read-back of the d_len_out == NULL form goes into a page-locked word the scene has held since
+    its creation, not into pageable memory the runtime would stage."""
+    import torch
+    w = World.default()
+    scene = w.scene()
+    rgb = torch.rand((40, 50, 3), dtype=torch.float64, device="cuda:0")
+    q = torch.zeros((40, 50, 3), dtype=torch.uint8, device="cuda:0")
+    text = torch.zeros((40 * 50 * 12 + 64,), dtype=torch.uint8, device="cuda:0")
+    length = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    args = (scene, rgb.data_ptr(), 50, 40, q.data_ptr(), text.data_ptr(), text.numel())
+    n0 = rt.lib.rt_canvas_to_ppm_noalloc(*args, None, None)     # first call: whatever is lazily set up happens here
+    assert n0 > 0, rt.last_error()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(20):
+        assert rt.lib.rt_canvas_to_ppm_noalloc(*args, None, None) == n0
+        assert rt.lib.rt_canvas_to_ppm_noalloc(*args, length.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 == free0, (free0, free1)
+    assert int(length.item()) == n0
+
+
 def test_noalloc_ppm_limits():
     import torch
     w = World.default()
