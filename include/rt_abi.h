@@ -411,6 +411,43 @@ int rt_intersect_world(rt_scene* scene, int64_t n_rays, const double* origins, c
 /* World::is_shadowed (src/world.rs:92-107) for a batch of points: out [n_points][n_lights], 1 = shadowed. */
 int rt_is_shadowed(rt_scene* scene, int64_t n_points, const double* points, uint8_t* out);
 
+/* ---- the path's inner functions, one entry point each: what the reference's own unit tests call directly
+ * (src/intersection.rs:235-410, src/shape.rs:678-730, src/material.rs:161-277, src/pattern.rs:226-426), so that their
+ * vectors can be replayed on the device without an oracle in between (tests/test_gpu_kats.py). ---- */
+
+/* columns of rt_prepare_computations' output rows — struct Computations, src/computations.rs:6-18 */
+#define RT_COMP_T 0
+#define RT_COMP_POINT 1    /* 3 */
+#define RT_COMP_EYE 4      /* 3 */
+#define RT_COMP_NORMAL 7   /* 3 */
+#define RT_COMP_INSIDE 10  /* 0.0 / 1.0 */
+#define RT_COMP_OVER 11    /* 3 */
+#define RT_COMP_UNDER 14   /* 3 */
+#define RT_COMP_REFLECT 17 /* 3 */
+#define RT_COMP_N1 20
+#define RT_COMP_N2 21
+#define RT_COMP_SCHLICK 22 /* Intersection::schlick(comps), src/intersection.rs:97-115 */
+#define RT_COMP_U 23       /* the u, v normal_at was given: those of intersections[0] (src/intersection.rs:40) */
+#define RT_COMP_V 24
+#define RT_COMP_COUNT 25
+
+/* Intersection::prepare_computations (src/intersection.rs:38-95) for `Intersection::hit(world.intersect_world(ray))` of
+ * each ray (host buffers): hit_id_out [n_rays] object id of the hit (0: no hit, the row is zero), comps_out
+ * [n_rays][RT_COMP_COUNT], flags_out nullable.  The n1/n2 walk runs for every hit, as in the reference. */
+int rt_prepare_computations(rt_scene* scene, int64_t n_rays, const double* origins, const double* directions, int32_t* hit_id_out,
+                            double* comps_out, uint8_t* flags_out);
+
+/* Shape::normal_at (src/shape.rs:92-108: world_to_object down the parent chain, the kind's local normal, normal_to_world
+ * back up) of leaf node `node` (index into rt_scene_desc's node tables) for world points [n][3] -> normals_out [n][3]
+ * (host buffers); uv nullable [n][2]: the u, v a SmoothTriangle interpolates with (src/smooth_triangle.rs:98-104). */
+int rt_normal_at(rt_scene* scene, int32_t node, int64_t n, const double* points, const double* uv, double* normals_out);
+
+/* Material::lighting (src/material.rs:97-129) with the material of leaf node `node` (its root ancestor's, F7; a pattern is
+ * evaluated through Pattern::pattern_at_shape, src/pattern.rs:23-35, i.e. in the leaf's object space) and light `light`:
+ * points / eyes / normals [n][3], in_shadow [n] -> rgb_out [n][3] (host buffers). */
+int rt_lighting(rt_scene* scene, int32_t node, int32_t light, int64_t n, const double* points, const double* eyes,
+                const double* normals, const uint8_t* in_shadow, double* rgb_out);
+
 /* Canvas::canvas_to_ppm (src/canvas.rs:33-84) + scale_color (src/canvas.rs:86-98) on the device, byte for byte:
  * "P3\n{w} {h}\n255\n", then per canvas row the 3*w quantised values, a value that would make a line reach 70
  * characters starts a new line, every row ends its line.  d_rgb_frame: DEVICE pointer, row-major vsize x hsize x 3 f64

@@ -92,6 +92,7 @@ struct rt_scene {
     DScene ds{};
     std::vector<void*> allocs;
     bool has_csg = false, has_smooth = false, any_transparent = false;
+    std::vector<int32_t> leaf_kind;  // host copy of the node kinds (argument checks of rt_normal_at / rt_lighting)
     int meshes_built_on_gpu = 0;
     int meshes_shared = 0;
     int scene_class = 0;  // SC_CSG | SC_CULL: which traversal kernel variants this scene runs
@@ -1113,6 +1114,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
 #undef UP
     s->ds.n_lights = d.n_lights;
     s->ds.n_nodes = d.n_nodes;
+    s->leaf_kind = vec_of(d.node_kind, size_t(d.n_nodes));
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
     s->ds.cull_reach = prog.cull_reach;
@@ -1879,6 +1881,88 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
                      ARENA_ROUNDS[N_ARENA_ROUNDS - 1].csg_cap);
         return RT_ERR_OVERFLOW;
     }
+    return RT_OK;
+}
+
+int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t* hit_id_out,
+                            double* comps_out, uint8_t* flags_out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n_rays < 0 || !origins || !directions || !hit_id_out || !comps_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    if (n_rays == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    int rc;
+    const size_t rb = size_t(n_rays) * 3 * sizeof(double), cb = size_t(n_rays) * RT_COMP_COUNT * sizeof(double);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->misc_a, size_t(n_rays) * sizeof(int32_t))) != RT_OK ||
+        (rc = grow(s->misc_b, cb)) != RT_OK || (rc = grow(s->out_flags, size_t(n_rays))) != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
+    const double* o = static_cast<const double*>(s->in_a.p);
+    const double* d = static_cast<const double*>(s->in_b.p);
+    int32_t* ids = static_cast<int32_t*>(s->misc_a.p);
+    double* comps = static_cast<double*>(s->misc_b.p);
+    uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
+    if (s->has_csg) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
+    else rc = launch_trav(s, st, k_comps<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hit_id_out, ids, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(comps_out, comps, cb, hipMemcpyDeviceToHost, st));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, fl, size_t(n_rays), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+static int leaf_node_arg(rt_scene* s, int32_t node) {
+    if (node < 0 || node >= s->ds.n_nodes || s->leaf_kind.empty() || s->leaf_kind[size_t(node)] > RT_SMOOTH_TRIANGLE) {
+        rt_set_error("node %d is not a leaf (primitive) node of this scene", node);
+        return RT_ERR_BAD_ARG;
+    }
+    return RT_OK;
+}
+
+int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, const double* uv, double* normals_out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n < 0 || !points || !normals_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    int rc = leaf_node_arg(s, node);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    const size_t rb = size_t(n) * 3 * sizeof(double);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, size_t(n) * 2 * sizeof(double))) != RT_OK || (rc = grow(s->out_rgb, rb)) != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
+    if (uv) HIP_TRY(hipMemcpyAsync(s->in_b.p, uv, size_t(n) * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_normal_at, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (long long)n, static_cast<const double*>(s->in_a.p),
+                       uv ? static_cast<const double*>(s->in_b.p) : nullptr, static_cast<double*>(s->out_rgb.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(normals_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+int rt_lighting(rt_scene* s, int32_t node, int32_t light, int64_t n, const double* points, const double* eyes, const double* normals,
+                const uint8_t* in_shadow, double* rgb_out) {
+    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (n < 0 || !points || !eyes || !normals || !in_shadow || !rgb_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
+    int rc = leaf_node_arg(s, node);
+    if (rc != RT_OK) return rc;
+    if (light < 0 || light >= s->n_lights) { rt_set_error("light %d out of range (the world has %d)", light, s->n_lights); return RT_ERR_BAD_ARG; }
+    if (n == 0) return RT_OK;
+    hipStream_t st = s->stream;
+    const size_t rb = size_t(n) * 3 * sizeof(double);
+    if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->misc_b, rb)) != RT_OK ||
+        (rc = grow(s->misc_a, size_t(n))) != RT_OK || (rc = grow(s->out_rgb, rb)) != RT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->in_b.p, eyes, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->misc_b.p, normals, rb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->misc_a.p, in_shadow, size_t(n), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_lighting, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (int)light, (long long)n,
+                       static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), static_cast<const double*>(s->misc_b.p),
+                       static_cast<const uint8_t*>(s->misc_a.p), static_cast<double*>(s->out_rgb.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return RT_OK;
 }
 

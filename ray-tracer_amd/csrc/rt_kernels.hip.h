@@ -2016,6 +2016,100 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_shadow_points(DScene S, l
     }
 }
 
+// Kernel: Intersection::prepare_computations (src/intersection.rs:38-95) and Intersection::schlick (:97-115) for the hit
+// of each ray, every field of `Computations` (src/computations.rs:6-18) handed back (rt_prepare_computations).  The
+// same device functions the frame pipeline runs — traverse, normal_at_wave, container_walk, schlick — with nothing
+// skipped: the n1/n2 walk runs for every hit, as in the reference, whatever the material.
+template <int SC>
+__global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_comps(DScene S, long long n, const double* __restrict__ origins,
+                                                            const double* __restrict__ dirs, int32_t* hit_id_out, double* out, uint8_t* flags_out) {
+    Feed feed;
+    const TravMem M = trav_setup(S, feed, nullptr, (n + 63) / 64);
+    for (long long c = feed.next(); c >= 0; c = feed.next()) {
+        const long long i = c * 64 + (threadIdx.x & 63);
+        const bool alive = i < n;
+        Work w = {};
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        if (alive) {
+            o = mk(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+            d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+        }
+        ClosestSink<true> sink;
+        sink.init(INFINITY);
+        traverse<SC, false>(S, M, o, d, sink, w, alive);
+        const int key = alive ? sink.best_key : -1;
+        const bool hit = key >= 0;
+        const int node = hit ? key >> 2 : 0;
+        NodeRec rec = {0, 0, 0, 0};
+        if (hit) rec = S.node_rec[node];
+        rec.kind &= 0xff;
+        double u = sink.bu, v = sink.bv;
+        unsigned flags = alive ? sink.flags : 0;
+        if (hit && rec.kind == RT_SMOOTH_TRIANGLE) {
+            if (sink.first_uv) { u = sink.fu; v = sink.fv; }  // u,v of intersections[0] (F5)
+            else flags |= RT_FLAG_REF_PANIC_UV;
+        }
+        const V3 point = vadd(o, vmul(d, sink.best_t));
+        V3 normal_vector = normal_at_wave(S, hit, rec, point, u, v);
+        const V3 eye_vector = vneg(d);
+        const bool inside = hit && dot(normal_vector, eye_vector) < 0.;
+        if (inside) normal_vector = vneg(normal_vector);
+        double n1 = 0., n2 = 0.;
+        container_walk<SC, false>(S, M, o, d, hit ? sink.best_t : 0., node, w, n1, n2, flags, hit);
+        if (!alive) continue;
+        hit_id_out[i] = hit ? S.node_object_id[node] : 0;
+        flags_out[i] = (uint8_t)flags;
+        double* r = out + i * RT_COMP_COUNT;
+        if (!hit) {
+            for (int k = 0; k < RT_COMP_COUNT; ++k) r[k] = 0.;
+            continue;
+        }
+        const V3 over_point = over_point_of(point, normal_vector), under_point = under_point_of(point, normal_vector);
+        const V3 reflect_vector = reflect(d, normal_vector);
+        r[RT_COMP_T] = sink.best_t;
+        r[RT_COMP_POINT] = point.x; r[RT_COMP_POINT + 1] = point.y; r[RT_COMP_POINT + 2] = point.z;
+        r[RT_COMP_EYE] = eye_vector.x; r[RT_COMP_EYE + 1] = eye_vector.y; r[RT_COMP_EYE + 2] = eye_vector.z;
+        r[RT_COMP_NORMAL] = normal_vector.x; r[RT_COMP_NORMAL + 1] = normal_vector.y; r[RT_COMP_NORMAL + 2] = normal_vector.z;
+        r[RT_COMP_INSIDE] = inside ? 1. : 0.;
+        r[RT_COMP_OVER] = over_point.x; r[RT_COMP_OVER + 1] = over_point.y; r[RT_COMP_OVER + 2] = over_point.z;
+        r[RT_COMP_UNDER] = under_point.x; r[RT_COMP_UNDER + 1] = under_point.y; r[RT_COMP_UNDER + 2] = under_point.z;
+        r[RT_COMP_REFLECT] = reflect_vector.x; r[RT_COMP_REFLECT + 1] = reflect_vector.y; r[RT_COMP_REFLECT + 2] = reflect_vector.z;
+        r[RT_COMP_N1] = n1;
+        r[RT_COMP_N2] = n2;
+        r[RT_COMP_SCHLICK] = schlick(eye_vector, normal_vector, n1, n2);
+        r[RT_COMP_U] = u;
+        r[RT_COMP_V] = v;
+    }
+}
+
+// Kernel: Shape::normal_at (src/shape.rs:92-108) of one leaf node for a batch of world points (rt_normal_at); `uv` [n][2]
+// or null: the u, v of the intersection handed to SmoothTriangle::normal_at.  Whole wavefronts execute (normal_at_wave).
+__global__ __launch_bounds__(BLOCK) void k_normal_at(DScene S, int node, long long n, const double* __restrict__ points,
+                                                     const double* __restrict__ uv, double* out) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool on = i < n;
+    NodeRec rec = S.node_rec[node];
+    rec.kind &= 0xff;
+    const V3 p = on ? mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]) : mk(0., 0., 0.);
+    const double u = on && uv ? uv[2 * i] : 0., v = on && uv ? uv[2 * i + 1] : 0.;
+    const V3 nv = normal_at_wave(S, on, rec, p, u, v);
+    if (on) { out[3 * i] = nv.x; out[3 * i + 1] = nv.y; out[3 * i + 2] = nv.z; }
+}
+
+// Kernel: Material::lighting (src/material.rs:97-129) with the material (and pattern, evaluated in the leaf's object
+// space: Pattern::pattern_at_shape, src/pattern.rs:23-35) of one leaf node, for a batch of (point, eye, normal, in_shadow).
+__global__ __launch_bounds__(BLOCK) void k_lighting(DScene S, int node, int light, long long n, const double* __restrict__ points,
+                                                    const double* __restrict__ eyes, const double* __restrict__ normals,
+                                                    const uint8_t* __restrict__ in_shadow, double* out) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int mi = S.node_material[node];
+    const V3 c = lighting(S, S.mat + (size_t)mi * RT_MAT_STRIDE, S.mat_pattern[mi], node, light, mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]),
+                          mk(eyes[3 * i], eyes[3 * i + 1], eyes[3 * i + 2]), mk(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]),
+                          in_shadow[i] != 0);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Canvas::canvas_to_ppm on the device (src/canvas.rs:33-98).  Every value is followed by exactly one separator
 // (' ', or '\n' where the reference wraps or ends the row), so a row's byte length is the sum of (digits + 1) over

@@ -82,6 +82,12 @@ RT_PAT_STRIPED, RT_PAT_GRADIENT, RT_PAT_RING, RT_PAT_CHECKERED, RT_PAT_RING_GRAD
 RT_FLAG_REF_PANIC_UV, RT_FLAG_NAN_T, RT_FLAG_LIST_OVERFLOW = 1, 2, 4
 RT_OK, RT_ERR_BAD_ARG, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
 
+# columns of rt_prepare_computations' rows (rt_abi.h RT_COMP_*)
+RT_COMP_COUNT = 25
+COMP = {"t": slice(0, 1), "point": slice(1, 4), "eye": slice(4, 7), "normal": slice(7, 10), "inside": slice(10, 11), "over": slice(11, 14),
+        "under": slice(14, 17), "reflect": slice(17, 20), "n1": slice(20, 21), "n2": slice(21, 22), "schlick": slice(22, 23),
+        "u": slice(23, 24), "v": slice(24, 25)}
+
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
 c_bp = C.POINTER(C.c_uint8)
@@ -159,7 +165,7 @@ class CMaterial(C.Structure):  # rth_material
 
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
 ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_begin", "rt_render_end", "rt_shard_pixel_count",
-               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_quantise", "rt_assemble_quantised", "rt_color_at", "rt_intersect_world", "rt_is_shadowed",
+               "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_quantise", "rt_assemble_quantised", "rt_color_at", "rt_intersect_world", "rt_is_shadowed", "rt_prepare_computations", "rt_normal_at", "rt_lighting",
                "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi", "rt_host_alloc", "rt_host_free",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
 HOST_SYMBOLS = ["rth_identity", "rth_translate", "rth_scale", "rth_rotate", "rth_shear", "rth_view_transform",
@@ -199,6 +205,9 @@ lib.rt_assemble_quantised.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.c_int
 lib.rt_color_at.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_dp, c_ip, c_bp, C.POINTER(Stats)]
 lib.rt_intersect_world.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, C.c_int32, c_ip, c_dp, c_ip]
 lib.rt_is_shadowed.argtypes = [C.c_void_p, C.c_int64, c_dp, c_bp]
+lib.rt_prepare_computations.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_ip, c_dp, c_bp]
+lib.rt_normal_at.argtypes = [C.c_void_p, C.c_int32, C.c_int64, c_dp, c_dp, c_dp]
+lib.rt_lighting.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, c_dp, c_dp, c_dp, c_bp, c_dp]
 lib.rt_ray_for_pixel.argtypes = [C.POINTER(CameraDesc), C.c_int64, c_ip, c_ip, c_dp, c_dp]
 lib.rt_canvas_to_ppm.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_int64]
 lib.rt_canvas_to_ppm.restype = C.c_int64
@@ -723,6 +732,36 @@ class World:
     def intersect_world(self, ray):
         cnt, t, ids = self.intersect_world_batch([ray[0]], [ray[1]])
         return [(float(t[0, k]), int(ids[0, k])) for k in range(int(cnt[0]))]
+
+    # Intersection::prepare_computations (src/intersection.rs:38-95) for the hit of each ray
+    def prepare_computations_batch(self, origins, directions):
+        """Returns (hit object ids [n], comps [n, RT_COMP_COUNT], flags [n]); columns: COMP dict below."""
+        o = np.ascontiguousarray(np.asarray(origins, dtype=np.float64).reshape(-1, 3))
+        d = np.ascontiguousarray(np.asarray(directions, dtype=np.float64).reshape(-1, 3))
+        n = len(o)
+        ids = np.zeros(n, dtype=np.int32)
+        comps = np.zeros((n, RT_COMP_COUNT))
+        flags = np.zeros(n, dtype=np.uint8)
+        _chk(lib.rt_prepare_computations(self.scene(), n, _dp(o), _dp(d), ids.ctypes.data_as(c_ip), _dp(comps), flags.ctypes.data_as(c_bp)))
+        return ids, comps, flags
+
+    # Shape::normal_at (src/shape.rs:92-108)
+    def normal_at_batch(self, shape, points, uv=None):
+        p = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        q = None if uv is None else np.ascontiguousarray(np.asarray(uv, dtype=np.float64).reshape(-1, 2))
+        out = np.zeros_like(p)
+        _chk(lib.rt_normal_at(self.scene(), self.node_of(shape), len(p), _dp(p), None if q is None else _dp(q), _dp(out)))
+        return out
+
+    # Material::lighting (src/material.rs:97-129) with `shape`'s material
+    def lighting_batch(self, shape, light, points, eyes, normals, in_shadow):
+        p = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        e = np.ascontiguousarray(np.asarray(eyes, dtype=np.float64).reshape(-1, 3))
+        nn = np.ascontiguousarray(np.asarray(normals, dtype=np.float64).reshape(-1, 3))
+        sh = np.ascontiguousarray(np.asarray(in_shadow, dtype=np.uint8).reshape(-1))
+        out = np.zeros_like(p)
+        _chk(lib.rt_lighting(self.scene(), self.node_of(shape), int(light), len(p), _dp(p), _dp(e), _dp(nn), sh.ctypes.data_as(c_bp), _dp(out)))
+        return out
 
     # World::is_shadowed (src/world.rs:92-107)
     def is_shadowed_batch(self, points):

@@ -1,0 +1,478 @@
+"""The reference's own unit-test vectors (tests/golden/reference_kats.json, transcribed from the `#[cfg(test)]` modules
+of ashcolecarr/Ray-Tracer; each table names its file:line) replayed ON THE DEVICE through the C ABI — no oracle in
+between.  tests/test_oracle_kats.py pins the oracle to the same tables; this file pins the HIP path to them directly:
+primitives through rt_intersect_world on single-leaf worlds, prepare_computations / n1-n2 / schlick through
+rt_prepare_computations, normals and the parent chain through rt_normal_at, lighting and patterns through rt_lighting,
+shading / reflection / refraction through rt_color_at at remaining 0 / 5, the Group gate and the CSG rule table through
+rays.  Tolerance 1e-5 = the reference's near_eq (src/lib.rs:56-62)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import rt_amd as rt
+from rt_amd import COMP, Axis, Camera, Light, Material, Pattern, Shape, World, rotate, scale, translate, view_transform
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+EPS = 1e-5
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as _f:
+    KAT = json.load(_f)
+
+
+def near(a, b, eps=EPS):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return a.shape == b.shape and bool(np.all(np.abs(a - b) < eps))
+
+
+def norm(v):
+    v = np.asarray(v, dtype=float)
+    return tuple(v / np.sqrt((v * v).sum()))
+
+
+def world_of(*shapes, lights=None):
+    w = World()
+    w.objects += list(shapes)
+    w.lights += lights if lights is not None else [Light.point_light((-10., 10., -10.), rt.WHITE)]
+    return w
+
+
+def ts(world, origin, direction):
+    """t values of World::intersect_world (a single untransformed leaf: Shape::intersect's local list, sorted)."""
+    return [t for t, _ in world.intersect_world((tuple(origin), tuple(direction)))]
+
+
+def comps(world, origin, direction):
+    ids, c, flags = world.prepare_computations_batch([origin], [direction])
+    return int(ids[0]), c[0], int(flags[0])
+
+
+# ------------------------------------------------------------------ camera.rs
+def test_camera_tables():  # camera.rs:108-178
+    for c in KAT["camera_pixel_size"]["cases"]:
+        assert abs(Camera(c["hsize"], c["vsize"], c["fov"]).desc().pixel_size - c["pixel_size"]) < EPS
+    k = KAT["camera_ray_for_pixel"]
+    for c in k["cases"]:
+        cam = Camera(k["hsize"], k["vsize"], k["fov"])
+        if c["transform"]:
+            cam.transform = rotate(PI / 4, Axis.Y) * translate(0., -2., 5.)
+        o, d = cam.ray_for_pixel(c["px"], c["py"])
+        assert near(o, c["origin"]) and near(d, c["direction"])
+    k = KAT["camera_render_default_world"]
+    cam = Camera(k["hsize"], k["vsize"], k["fov"])
+    cam.transform = view_transform(k["from"], k["to"], k["up"])
+    assert near(cam.render(World.default()).pixel_at(*k["pixel"]), k["color"])
+
+
+# ------------------------------------------------------------------ world.rs
+def test_world_tables():  # world.rs:186-326, 575-588
+    w = World.default()
+    assert ts(w, *KAT["world_intersect"]["ray"]) == KAT["world_intersect"]["t"]
+    k = KAT["world_shade_hit_outside"]          # the hit the reference hands to shade_hit IS the ray's hit: color_at
+    assert near(w.color_at((tuple(k["ray"][0]), tuple(k["ray"][1]))), k["color"])
+    k = KAT["world_shade_hit_inside"]
+    w2 = World.default()
+    w2.lights[0] = Light.point_light(k["light"], rt.WHITE)
+    assert near(w2.color_at((tuple(k["ray"][0]), tuple(k["ray"][1]))), k["color"])
+    k = KAT["world_color_at"]
+    assert near(w.color_at((tuple(k["miss_ray"][0]), tuple(k["miss_ray"][1]))), k["miss"])
+    assert near(w.color_at((tuple(k["hit_ray"][0]), tuple(k["hit_ray"][1]))), k["hit"])
+    w3 = World.default()
+    for o in w3.objects:
+        m = o.get_material()
+        m.ambient = 1.
+        o.set_material(m)
+    assert near(w3.color_at((tuple(k["behind_ray"][0]), tuple(k["behind_ray"][1]))), w3.objects[1].get_material().color)
+    for c in KAT["world_is_shadowed"]["cases"]:
+        assert w.is_shadowed(c["point"]) == [c["shadowed"]]
+    k = KAT["world_shade_hit_in_shadow"]
+    s2 = Shape.sphere().set_transform(translate(*k["s2_translate"]))
+    w4 = world_of(Shape.sphere(), s2, lights=[Light.point_light(k["light"], rt.WHITE)])
+    assert near(w4.color_at((tuple(k["ray"][0]), tuple(k["ray"][1]))), k["color"])
+    k = KAT["world_no_shadow_when_not_casting"]
+    sphere = Shape.sphere().set_transform(translate(*k["sphere_translate"])).set_casts_shadow(False)
+    w5 = world_of(sphere, Shape.plane(), lights=[Light.point_light(k["light"], rt.WHITE)])
+    assert w5.is_shadowed(k["point"]) == [k["shadowed"]]
+
+
+def test_reflection_tables():  # world.rs:329-429: reflected_color = shade_hit(remaining) - shade_hit(0) for an opaque mirror
+    k = KAT["world_reflection"]
+    ray = (tuple(k["ray45"][0]), tuple(k["ray45"][1]))
+    w = World.default()
+    w.objects.append(Shape.plane().set_material(Material(reflective=k["reflective"])).set_transform(translate(*k["plane_translate"])))
+    full, none = np.array(w.color_at(ray, 5)), np.array(w.color_at(ray, 0))
+    assert near(full, k["shade_hit"])
+    assert near(full - none, k["reflected"])          # reflected_color(comps, 5); at remaining 0 it is `at_max_depth` = BLACK
+    ids, c, _ = w.prepare_computations_batch([ray[0]], [ray[1]])
+    assert abs(c[0][COMP["t"]][0] - k["t"]) < EPS
+    # a non-reflective surface: color_at does not depend on `remaining` (world.rs:329-345)
+    w = World.default()
+    m = w.objects[1].get_material()
+    m.ambient = 1.
+    w.objects[1].set_material(m)
+    r = ((0, 0, 0), (0, 0, 1))
+    assert near(np.array(w.color_at(r, 5)) - np.array(w.color_at(r, 0)), k["nonreflective"])
+
+
+def test_refraction_tables():  # world.rs:432-572: refracted_color * transparency = shade_hit(5) - shade_hit(0) for non-mirrors
+    k = KAT["world_refraction"]
+    w = World.default()                               # opaque: nothing is added at any depth
+    r = ((0, 0, -5), (0, 0, 1))
+    assert near(np.array(w.color_at(r, 5)) - np.array(w.color_at(r, 0)), k["opaque"])
+    w = World.default()                               # total internal reflection (world.rs:466-485)
+    w.objects[0].set_material(Material(color=(0.8, 1., 0.6), diffuse=0.7, specular=0.2, transparency=1., refractive_index=1.5))
+    r = (tuple(k["tir_ray"][0]), tuple(k["tir_ray"][1]))
+    assert near(ts(w, *r), k["tir_xs"])               # the inner sphere (radius 0.5) is not on this line
+    assert near(np.array(w.color_at(r, 5)) - np.array(w.color_at(r, 0)), k["total_internal_reflection"])
+    w = World.default()                               # the refracted ray, seen through a TestPattern (world.rs:488-511)
+    w.objects[0].set_material(Material(ambient=1.).with_pattern(Pattern.test()))
+    w.objects[1].set_material(Material(transparency=1., refractive_index=1.5))
+    r = (tuple(k["refracted_ray"][0]), tuple(k["refracted_ray"][1]))
+    assert near(ts(w, *r), k["refracted_xs"], 1e-4)
+    assert near(np.array(w.color_at(r, 5)) - np.array(w.color_at(r, 0)), k["refracted"])      # transparency is 1.0
+    ray45 = (tuple(KAT["world_reflection"]["ray45"][0]), tuple(KAT["world_reflection"]["ray45"][1]))
+    for mat, key in ((dict(transparency=0.5, refractive_index=1.5), "transparent_floor"),
+                     (dict(reflective=0.5, transparency=0.5, refractive_index=1.5), "schlick_floor")):
+        w = World.default()
+        w.objects.append(Shape.plane().set_transform(translate(0, -1, 0)).set_material(Material(**mat)))
+        w.objects.append(Shape.sphere().set_material(Material(color=(1, 0, 0), ambient=0.5)).set_transform(translate(0, -3.5, -0.5)))
+        assert near(w.color_at(ray45), k[key])
+
+
+# ------------------------------------------------------------------ intersection.rs
+def test_prepare_computations_tables():  # intersection.rs:235-320
+    s = Shape.sphere()
+    w = world_of(s)
+    for which in ("outside", "inside"):
+        k = KAT["prepare_computations"][which]
+        hit, c, _ = comps(w, *k["ray"])
+        assert hit == s.get_id() and abs(c[COMP["t"]][0] - k["t"]) < EPS
+        assert near(c[COMP["point"]], k["point"]) and near(c[COMP["eye"]], k["eye"]) and near(c[COMP["normal"]], k["normal"])
+        assert bool(c[COMP["inside"]][0]) == k["inside"]
+        if which == "outside":
+            assert c[COMP["n1"]][0] == 1. and c[COMP["n2"]][0] == 1.
+    k = KAT["prepare_computations"]["reflect"]
+    p = Shape.plane()
+    hit, c, _ = comps(world_of(p), *k["ray"])
+    assert hit == p.get_id() and abs(c[COMP["t"]][0] - k["t"]) < EPS and near(c[COMP["reflect"]], k["reflect"])
+    # over / under point (intersection.rs:297-306, 356-366)
+    g = Shape.glass_sphere().set_transform(translate(0, 0, 1))
+    _, c, _ = comps(world_of(g), (0, 0, -5), (0, 0, 1))
+    assert c[COMP["over"]][2] < -EPS / 2 and c[COMP["point"]][2] > c[COMP["over"]][2]
+    assert c[COMP["under"]][2] > EPS / 2 and c[COMP["point"]][2] < c[COMP["under"]][2]
+    # a miss: hit id 0, zero row
+    hit, c, _ = comps(w, (0, 5, -5), (0, 0, 1))
+    assert hit == 0 and not c.any()
+
+
+def test_n1_n2_table():  # intersection.rs:323-353
+    """The reference passes the list (2 A, 2.75 B, 3.25 C, 4.75 B, 5.25 C, 6 A) literally (its shapes' transforms and its
+    ray's direction do not produce it); here the book's three glass spheres do: A scaled by 2, B at z = -0.25, C at z = +0.25."""
+    k = KAT["n1_n2"]
+    a = Shape.glass_sphere().set_transform(scale(2, 2, 2))
+    b = Shape.glass_sphere().set_transform(translate(0, 0, -0.25)).set_material(Material(refractive_index=k["indices"]["b"]))
+    c_ = Shape.glass_sphere().set_transform(translate(0, 0, 0.25)).set_material(Material(refractive_index=k["indices"]["c"]))
+    w = world_of(a, b, c_)
+    o, d = k["ray"]
+    d = (0, 0, 1)   # the reference's ray is (0,0,-4) -> (0,0,1): xs 2, 2.75, 3.25, 4.75, 5.25, 6
+    assert near(ts(w, o, d), [x[0] for x in k["xs"]])
+    ids = {"a": a.get_id(), "b": b.get_id(), "c": c_.get_id()}
+    for i, ((t_i, name), (n1, n2)) in enumerate(zip(k["xs"], k["expected"])):
+        # prepare_computations(xs[i], ray, xs): the same line of intersections seen from just before xs[i] — the walk runs
+        # over ALL entries (the ones behind the origin too), so n1 / n2 of entry i do not depend on where the ray starts
+        origin = (o[0], o[1], o[2] + t_i - 0.1)
+        hit, c, _ = comps(w, origin, d)
+        assert hit == ids[name] and abs(c[COMP["t"]][0] - 0.1) < EPS
+        assert abs(c[COMP["n1"]][0] - n1) < EPS and abs(c[COMP["n2"]][0] - n2) < EPS, (i, c[COMP["n1"]], c[COMP["n2"]])
+
+
+def test_schlick_table():  # intersection.rs:369-410
+    """The reference hands prepare_computations literal intersection lists; here the same lists come from geometry.  Case 1:
+    the reference's ray starts at z = sqrt(2) (a typo for the book's sqrt(2)/2: its own list, -+sqrt(2)/2, is what a ray
+    from sqrt(2)/2 meets) — total internal reflection, reflectance 1, either way; the ray is started where the list says."""
+    s = Shape.glass_sphere()
+    w = world_of(s)
+    for i, c in enumerate(KAT["schlick"]["cases"]):
+        o, d = c["ray"]
+        if i == 0:
+            o = [0., 0., c["xs"][1]]
+        got = ts(w, o, d)
+        assert all(any(abs(t - x) < 1e-4 for t in got) for x in c["xs"])     # the table's entries are on the real line
+        hit, row, _ = comps(w, o, d)      # in all three cases the reference's hit is the ray's first t > 0
+        assert hit == s.get_id() and abs(row[COMP["t"]][0] - c["xs"][c["hit"]]) < 1e-4
+        assert abs(row[COMP["schlick"]][0] - c["reflectance"]) < EPS
+
+
+# ------------------------------------------------------------------ primitives: local intersect and local normal tables
+def test_sphere_tables():  # sphere.rs:107-196
+    s = Shape.sphere()
+    w = world_of(s)
+    k = KAT["sphere"]
+    for c in k["hits"]:
+        assert near(ts(w, c["origin"], k["direction"]), c["t"])
+    assert ts(w, k["miss_origin"], k["direction"]) == []
+    assert near(ts(world_of(Shape.sphere().set_transform(scale(2, 2, 2))), (0, 0, -5), (0, 0, 1)), k["scaled2_t"])
+    assert ts(world_of(Shape.sphere().set_transform(translate(5, 0, 0))), (0, 0, -5), (0, 0, 1)) == []
+    # normals (sphere.rs:199-260): on a unit sphere at the origin normal_at(p) = p
+    r3 = math.sqrt(3) / 3
+    pts = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (r3, r3, r3)]
+    assert near(w.normal_at_batch(s, pts), pts)
+
+
+def test_plane_tables():  # plane.rs:93-144
+    p = Shape.plane()
+    w = world_of(p)
+    k = KAT["plane"]
+    for o, d in k["misses"]:
+        assert ts(w, o, d) == []
+    for c in k["hits"]:
+        assert near(ts(w, *c["ray"]), [c["t"]])
+    assert near(w.normal_at_batch(p, [k["normal_at"][0]])[0], k["normal_at"][1])
+
+
+def test_cube_tables():  # cube.rs:108-185
+    c = Shape.cube()
+    w = world_of(c)
+    k = KAT["cube"]
+    for o, d, expect in k["hits"]:
+        assert near(ts(w, o, d), expect)
+    for o, d in k["misses"]:
+        assert ts(w, o, d) == []
+    pts = [p for p, _ in k["normals"]]
+    got = w.normal_at_batch(c, pts)
+    for (p, n), g in zip(k["normals"], got):   # the local normal keeps the component's VALUE (cube.rs:81-92); world normal = normalised
+        assert near(g, norm(n))
+
+
+def test_cylinder_tables():  # cylinder.rs:145-311
+    cyl = Shape.cylinder()
+    w = world_of(cyl)
+    k = KAT["cylinder"]
+    for o, d in k["misses"]:
+        assert ts(w, o, norm(d)) == []
+    for o, d, expect in k["hits"]:
+        assert near(ts(w, o, norm(d)), expect)
+    assert near(w.normal_at_batch(cyl, [p for p, _ in k["normals"]]), [n for _, n in k["normals"]])
+    tr = k["truncated"]
+    trunc = Shape.cylinder().set_minimum(tr["minimum"]).set_maximum(tr["maximum"])
+    w = world_of(trunc)
+    assert [len(ts(w, o, norm(d))) for o, d in tr["rays"]] == tr["counts"]
+    cp = k["capped"]
+    capped = Shape.cylinder().set_minimum(cp["minimum"]).set_maximum(cp["maximum"]).set_closed(True)
+    w = world_of(capped)
+    assert [len(ts(w, o, norm(d))) for o, d in cp["rays"]] == cp["counts"]
+    assert near(w.normal_at_batch(capped, [p for p, _ in cp["cap_normals"]]), [n for _, n in cp["cap_normals"]])
+
+
+def test_cone_tables():  # cone.rs:156-236
+    cone = Shape.cone()
+    w = world_of(cone)
+    k = KAT["cone"]
+    for o, d, expect in k["hits"]:
+        assert near(ts(w, o, norm(d)), expect)
+    t = ts(w, k["parallel_to_half"]["ray"][0], norm(k["parallel_to_half"]["ray"][1]))
+    assert len(t) == 1 and abs(t[0] - k["parallel_to_half"]["t"]) < EPS
+    cp = k["capped"]
+    capped = Shape.cone().set_minimum(cp["minimum"]).set_maximum(cp["maximum"]).set_closed(True)
+    w2 = world_of(capped)
+    assert [len(ts(w2, o, norm(d))) for o, d in cp["rays"]] == cp["counts"]
+    got = w.normal_at_batch(cone, [p for p, _ in k["normals"]])
+    for (p, n), g in zip(k["normals"], got):
+        if not any(n):
+            # local normal (0,0,0) at the apex (cone.rs:229): Shape::normal_at normalises it, 0/0 — NaN in the reference too
+            assert np.isnan(g).all()
+        else:
+            assert near(g, norm(n))
+
+
+def test_triangle_tables():  # triangle.rs:105-195, smooth_triangle.rs:151-196
+    k = KAT["triangle"]
+    t = Shape.triangle(*k["points"])
+    w = world_of(t)
+    assert near(w.normal_at_batch(t, k["normal_points"]), [k["normal"]] * len(k["normal_points"]))
+    for o, d in k["misses"]:   # parallel, p1-p3 edge, p1-p2 edge, p2-p3 edge
+        assert ts(w, o, d) == []
+    assert near(ts(w, *k["hit"]["ray"]), [k["hit"]["t"]])
+    k = KAT["smooth_triangle"]
+    st = Shape.smooth_triangle(*(k["points"] + k["normals"]))
+    w = world_of(st)
+    hit, c, flags = comps(w, *k["ray"])
+    assert hit == st.get_id() and flags == 0
+    assert abs(c[COMP["u"]][0] - k["u"]) < EPS and abs(c[COMP["v"]][0] - k["v"]) < EPS      # an intersection stores u, v
+    # normal_at(point, intersection with u, v) and the same through prepare_computations (the eye is in front: no flip)
+    assert near(w.normal_at_batch(st, [(0, 0, 0)], uv=[(k["u"], k["v"])])[0], k["normal"])
+    assert near(c[COMP["normal"]], k["normal"])
+
+
+# ------------------------------------------------------------------ shape.rs parent chain, group.rs, bound.rs
+def test_parent_chain_tables():  # shape.rs:678-730
+    k = KAT["parent_chain"]
+    g1 = Shape.group().set_transform(rotate(PI / 2, Axis.Y))
+    g2 = Shape.group().set_transform(scale(2, 2, 2))
+    s = Shape.sphere().set_transform(translate(5, 0, 0)).set_material(Material(ambient=1., diffuse=0., specular=0.).with_pattern(Pattern.test()))
+    g2.add_child(s)
+    g1.add_child(g2)
+    g1.set_material(Material(ambient=1., diffuse=0., specular=0.).with_pattern(Pattern.test()))   # the ROOT's material is the one used (F7)
+    w = world_of(g1, lights=[Light.point_light((0, 0, -10), rt.WHITE)])
+    # world_to_object, seen through a TestPattern (colour = pattern-space point = object-space point): ambient 1, white light
+    p = k["world_to_object"]["point"]
+    got = w.lighting_batch(s, 0, [p], [(0, 0, -1)], [(0, 0, -1)], [1])[0]     # in shadow: ambient term only
+    assert near(got, k["world_to_object"]["expected"])
+    g1 = Shape.group().set_transform(rotate(PI / 2, Axis.Y))
+    g2 = Shape.group().set_transform(scale(1, 2, 3))
+    s = Shape.sphere().set_transform(translate(5, 0, 0))
+    g2.add_child(s)
+    g1.add_child(g2)
+    w = world_of(g1)
+    assert near(w.normal_at_batch(s, [k["normal_at"]["point"]])[0], k["normal_at"]["expected"])
+    # normal_to_world(s, n): on a sphere the local normal IS the object-space point, so hand normal_at the world point
+    # that maps to n — object_to_world = rotate_y(pi/2) * scale(1,2,3) * translate(5,0,0)
+    n = np.array(k["normal_to_world"]["normal"])
+    fwd = (rotate(PI / 2, Axis.Y) * scale(1, 2, 3) * translate(5, 0, 0)).m.reshape(4, 4)
+    wp = fwd @ np.array([n[0], n[1], n[2], 1.])
+    assert near(w.normal_at_batch(s, [wp[:3]])[0], k["normal_to_world"]["expected"])
+
+
+def test_group_tables():  # group.rs:192-300
+    assert world_of(Shape.group()).intersect_world(((0, 0, 0), (0, 0, 1))) == []
+    g = Shape.group()
+    s1 = Shape.sphere()
+    s2 = Shape.sphere().set_transform(translate(0, 0, -3))
+    s3 = Shape.sphere().set_transform(translate(5, 0, 0))
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    k = KAT["group"]
+    ids = {"s1": s1.get_id(), "s2": s2.get_id()}
+    r = k["three_spheres_ray"]
+    assert [i for _, i in world_of(g).intersect_world((tuple(r[0]), tuple(r[1])))] == [ids[n] for n in k["order"]]
+    g = Shape.group().set_transform(scale(2, 2, 2))
+    g.add_child(Shape.sphere().set_transform(translate(5, 0, 0)))
+    assert len(ts(world_of(g), *k["scaled_group_ray"])) == k["scaled_group_count"]
+    g = Shape.group()
+    g.add_child(Shape.sphere())
+    w = world_of(g)
+    assert ts(w, *k["gate_miss_ray"]) == [] and len(ts(w, *k["gate_hit_ray"])) == 2
+
+
+def test_bound_intersects_tables():  # bound.rs:279-342
+    """Bound::intersects as the device runs it: the gate of a Group whose box is the table's box.  The box is made by a
+    cube child that fills it exactly (Group::bounds_of = the child's parent-space box), so a ray passes the gate iff it
+    meets the box — and the cube inside reports two intersections exactly then."""
+    k = KAT["bound_intersects"]
+    for which, xf in (("unit_box", None), ("noncubic_box", translate(8., 1., 3.5) * scale(3., 3., 3.5))):
+        b = k[which]
+        cube = Shape.cube()
+        if xf is not None:
+            cube.set_transform(xf)
+        g = Shape.group()
+        g.add_child(cube)
+        w = world_of(g)
+        box = np.array(w.flatten().contents.group_box[0:6])
+        assert near(box[:3], b["min"]) and near(box[3:], b["max"])
+        got = [len(ts(w, o, norm(d))) > 0 for o, d in zip(b["origins"], k["directions"])]
+        assert got == k["expected"], which
+
+
+# ------------------------------------------------------------------ csg.rs
+def test_csg_rule_table_through_rays():  # csg.rs:176-240
+    """intersection_allowed(op, left_hit, inside_left, inside_right) for all 24 rows.  Two overlapping spheres give the
+    line L1 R1 L2 R2 (t = 4, 4.5, 6, 6.5); swapping the operands gives R1 L1 R2 L2: between them the filter's loop
+    (csg.rs:106-126) meets all eight (left_hit, inl, inr) states, and which entries survive is read off the table."""
+    order = [(lh, il, ir) for lh in (True, False) for il in (True, False) for ir in (True, False)]   # the table's row order
+    for op in ("union", "intersection", "difference"):
+        allowed = dict(zip(order, (bool(x) for x in KAT["csg_truth_table"][op])))
+        seen = set()
+        for left_first in (True, False):
+            a = Shape.sphere()                                        # t = 4, 6
+            b = Shape.sphere().set_transform(translate(0, 0, 0.5))    # t = 4.5, 6.5
+            csg = Shape.csg(op, a, b) if left_first else Shape.csg(op, b, a)
+            line = [(4., a), (4.5, b), (6., a), (6.5, b)]
+            left = a if left_first else b
+            inl = inr = False
+            expect = []
+            for t, shape in line:                                     # filter_intersections replayed with the TABLE as the rule
+                lhit = shape is left
+                seen.add((lhit, inl, inr))
+                if allowed[(lhit, inl, inr)]:
+                    expect.append((t, shape.get_id()))
+                if lhit:
+                    inl = not inl
+                else:
+                    inr = not inr
+            got = world_of(csg).intersect_world(((0, 0, -5), (0, 0, 1)))
+            assert len(got) == len(expect) and all(abs(g[0] - e[0]) < EPS and g[1] == e[1] for g, e in zip(got, expect)), (op, left_first, got)
+        assert len(seen) == 8
+    for op, keep in KAT["csg_filter"]["expected"].items():            # csg.rs:223-240: (1,2,3,4) -> union 0,3 / ...
+        a, b = Shape.sphere(), Shape.sphere().set_transform(translate(0, 0, 0.5))
+        full = [4., 4.5, 6., 6.5]
+        assert near(ts(world_of(Shape.csg(op, a, b)), (0, 0, -5), (0, 0, 1)), [full[keep[0]], full[keep[1]]])
+    k = KAT["csg_rays"]
+    assert ts(world_of(Shape.csg("union", Shape.sphere(), Shape.cube())), *k["miss_ray"]) == []
+    s, c = Shape.sphere(), Shape.cube().set_transform(translate(*k["cube_translate"]))
+    xs = world_of(Shape.csg("union", s, c)).intersect_world((tuple(k["hit_ray"][0]), tuple(k["hit_ray"][1])))
+    assert len(xs) == 2 and near(xs[0][0], k["t"][0]) and xs[0][1] == s.get_id() and near(xs[1][0], k["t"][1]) and xs[1][1] == c.get_id()
+    # an unknown operation string allows nothing (csg.rs:102)
+    assert ts(world_of(Shape.csg("bogus", Shape.sphere(), Shape.cube())), (0, 0, -5), (0, 0, 1)) == []
+
+
+# ------------------------------------------------------------------ material.rs, pattern.rs
+def test_lighting_table():  # material.rs:161-277
+    k = KAT["lighting"]
+    for c in k["cases"]:
+        s = Shape.sphere()
+        w = world_of(s, lights=[Light.point_light(c["light"], rt.WHITE)])
+        got = w.lighting_batch(s, 0, [k["position"]], [c["eye"]], [k["normal"]], [c["shadow"]])[0]
+        assert near(got, c["color"], 1e-4)      # the table's 4-decimal literals (0.7364, 1.6364)
+    m = Material(ambient=1., diffuse=0., specular=0.).with_pattern(Pattern.striped(rt.WHITE, rt.BLACK))
+    s = Shape.sphere().set_material(m)
+    w = world_of(s, lights=[Light.point_light((0, 0, -10), rt.WHITE)])
+    for c in k["stripe"]:
+        assert near(w.lighting_batch(s, 0, [c["point"]], [(0, 0, -1)], [(0, 0, -1)], [0])[0], c["color"])
+
+
+def pattern_colour(pattern, points, transform=None):
+    """Pattern::pattern_at_shape through Material::lighting: ambient 1, no diffuse / specular, white light, in shadow."""
+    s = Shape.sphere().set_material(Material(ambient=1., diffuse=0., specular=0.).with_pattern(pattern))
+    if transform is not None:
+        s.set_transform(transform)
+    w = world_of(s)
+    n = len(points)
+    return w.lighting_batch(s, 0, points, [(0, 0, -1)] * n, [(0, 0, -1)] * n, [1] * n)
+
+
+def test_pattern_tables():  # pattern.rs:226-426
+    k = KAT["patterns"]
+    got = pattern_colour(Pattern.striped(rt.WHITE, rt.BLACK), [p for p, _ in k["stripe"]])
+    assert near(got, [[c] * 3 for _, c in k["stripe"]])
+    assert near(pattern_colour(Pattern.test(), [k["object_scale2"]["point"]], scale(2, 2, 2))[0], k["object_scale2"]["color"])
+    assert near(pattern_colour(Pattern.test().set_transform(scale(2, 2, 2)), [k["pattern_scale2"]["point"]])[0], k["pattern_scale2"]["color"])
+    assert near(pattern_colour(Pattern.test().set_transform(translate(0.5, 1, 1.5)), [k["both"]["point"]], scale(2, 2, 2))[0], k["both"]["color"])
+    got = pattern_colour(Pattern.gradient(rt.WHITE, rt.BLACK), [(x, 0, 0) for x, _ in k["gradient"]])
+    assert near(got, [[c] * 3 for _, c in k["gradient"]])
+    got = pattern_colour(Pattern.ring(rt.WHITE, rt.BLACK), [p for p, _ in k["ring"]])
+    assert near(got, [[c] * 3 for _, c in k["ring"]])
+    got = pattern_colour(Pattern.checkered(rt.WHITE, rt.BLACK), [p for p, _ in k["checkers"]])
+    assert near(got, [[c] * 3 for _, c in k["checkers"]])
+
+
+# ------------------------------------------------------------------ the three entry points against the oracle on random rays
+def test_prepare_computations_entry_point_matches_the_oracle_on_a_mixed_scene():
+    import oracle_bridge as ob
+    import scenes
+    w, _ = scenes.mixed_scene(32, 32)
+    rng = np.random.default_rng(5)
+    o = rng.normal(size=(400, 3)) * 4. + np.array([0., 1., 0.])
+    d = rng.normal(size=(400, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    ids, c, flags = w.prepare_computations_batch(o, d)
+    n_hit = 0
+    for i in range(len(o)):
+        xs = ob.intersect_world(w, (tuple(o[i]), tuple(d[i])))
+        pos = [(t, obj) for t, obj in xs if t > 0.]
+        assert ids[i] == (pos[0][1] if pos else 0)
+        if pos:
+            n_hit += 1
+            assert abs(c[i][0] - pos[0][0]) <= 1e-12 * max(1., abs(pos[0][0]))
+    assert n_hit > 50
