@@ -130,7 +130,8 @@ def test_refraction_tables():  # world.rs:432-572: refracted_color * transparenc
     w.objects[0].set_material(Material(ambient=1.).with_pattern(Pattern.test()))
     w.objects[1].set_material(Material(transparency=1., refractive_index=1.5))
     r = (tuple(k["refracted_ray"][0]), tuple(k["refracted_ray"][1]))
-    assert near(ts(w, *r), k["refracted_xs"], 1e-4)
+    got = ts(w, *r)     # the table's outer entries (-+0.9899) are the book's rounding of sqrt(0.99) = 0.99499: only their order matters
+    assert near(got[1:3], k["refracted_xs"][1:3], 1e-4) and near(got, k["refracted_xs"], 6e-3)
     assert near(np.array(w.color_at(r, 5)) - np.array(w.color_at(r, 0)), k["refracted"])      # transparency is 1.0
     ray45 = (tuple(KAT["world_reflection"]["ray45"][0]), tuple(KAT["world_reflection"]["ray45"][1]))
     for mat, key in ((dict(transparency=0.5, refractive_index=1.5), "transparent_floor"),
@@ -202,7 +203,10 @@ def test_schlick_table():  # intersection.rs:369-410
         assert all(any(abs(t - x) < 1e-4 for t in got) for x in c["xs"])     # the table's entries are on the real line
         hit, row, _ = comps(w, o, d)      # in all three cases the reference's hit is the ray's first t > 0
         assert hit == s.get_id() and abs(row[COMP["t"]][0] - c["xs"][c["hit"]]) < 1e-4
-        assert abs(row[COMP["schlick"]][0] - c["reflectance"]) < EPS
+        # case 3 grazes the sphere (cos = 0.14): the table's list holds t rounded to 1.8589 where the line really meets the
+        # sphere at 1.858930..., and (1 - cos)^5 turns those 3e-5 into 8e-5 of reflectance (the oracle test, which is handed
+        # the rounded t like the reference, agrees to 1e-5); 1e-4 there, the reference's own 1e-5 for the other two
+        assert abs(row[COMP["schlick"]][0] - c["reflectance"]) < (1e-4 if i == 2 else EPS)
 
 
 # ------------------------------------------------------------------ primitives: local intersect and local normal tables
