@@ -277,6 +277,12 @@ typedef struct rt_scene_opts {
                                                                                                [RT_AMD_FUSE_OUTPUT]    */
     int32_t fuse_spawn;         /* the launch that traces a level makes its reflection / refraction rays: -1/1 yes, 0 a
                                    k_spawn launch writes them first                             [RT_AMD_FUSE_SPAWN]    */
+    /* (struct_size >= 44) */
+    int32_t top_level_tree;     /* worlds with 64 or more bounded top-level objects: a BVH4 over the objects' world boxes,
+                                   walked per ray (nearest first, stack in LDS), names the objects a ray visits, instead of
+                                   nested cull ranges walked in program order; lanes whose rays meet different instances of
+                                   a mesh walk them side by side: -1/1 yes, 0 ranges only, 2 the tree without per-lane mesh
+                                   instances (every object left to the wavefront)                          [RT_AMD_TLAS]      */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is

@@ -91,7 +91,7 @@ struct rt_scene {
     hipStream_t stream = nullptr;
     DScene ds{};
     std::vector<void*> allocs;
-    bool has_csg = false, has_smooth = false, any_transparent = false;
+    bool has_csg = false, has_smooth = false, any_transparent = false, has_tlas = false;
     std::vector<int32_t> leaf_kind;  // host copy of the node kinds (argument checks of rt_normal_at / rt_lighting)
     int meshes_built_on_gpu = 0;
     int meshes_shared = 0;
@@ -321,7 +321,9 @@ inline long long chunks_for(long long n) { return (n + 63) / 64; }  // small lau
         case 0: CALL(0); break;     \
         case 1: CALL(1); break;     \
         case 2: CALL(2); break;     \
-        default: CALL(3); break;    \
+        case 3: CALL(3); break;     \
+        case 10: CALL(10); break;   \
+        default: CALL(11); break;   \
     }
 // k_trace: the closest hits of level L (n rays, or n_dev's count clamped to n; n == 0: none) and the shadow rays of
 // the hits of level P queued in `prev` (null: none); `prev_upper` bounds P's hit count for the grid size.
@@ -332,7 +334,7 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const
     int rc = RT_OK;
     if (s->big) {  // overflow fix-up: one variant serves every scene class (rt_kernels.hip.h: SC_BIG)
         if (COUNT) { rt_set_error("internal: the BIG variants are not instrumented"); return RT_ERR_BAD_ARG; }
-        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent);
+        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_TLAS | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent);
     }
 #define RT_CALL(SC)                                                                                                                      \
     rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent)    \
@@ -344,7 +346,7 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const
 template <bool COUNT>
 int launch_walk(rt_scene* s, hipStream_t st, const Level& L, long long n_upper, unsigned long long* ctr) {
     int rc = RT_OK;
-    if (s->big) return launch_trav(s, st, k_walk<SC_CSG | SC_CULL | SC_BIG, false>, chunks_for(n_upper), s->ds, L, ctr);
+    if (s->big) return launch_trav(s, st, k_walk<SC_CSG | SC_CULL | SC_TLAS | SC_BIG, false>, chunks_for(n_upper), s->ds, L, ctr);
 #define RT_CALL(SC) rc = launch_trav(s, st, k_walk<SC, COUNT>, chunks_for(n_upper), s->ds, L, ctr)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
@@ -978,7 +980,7 @@ namespace {
 // rt_scene_opts with every -1 resolved: the field, else its RT_AMD_* variable, else the default
 struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
-    bool share_meshes = true, fuse_output = true, fuse_spawn = true;
+    bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
 };
 void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
@@ -998,6 +1000,11 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     k.share_meshes = pick(v.share_meshes, "RT_AMD_SHARE_MESHES", true);
     k.fuse_output = pick(v.fuse_output, "RT_AMD_FUSE_OUTPUT", true);
     k.fuse_spawn = pick(v.fuse_spawn, "RT_AMD_FUSE_SPAWN", true);
+    k.tlas = pick(v.top_level_tree, "RT_AMD_TLAS", true);
+    {   // 2: the tree, but every object left to the wavefront (no per-lane mesh instances)
+        const char* e = std::getenv("RT_AMD_TLAS");
+        k.tlas_instances = !(v.top_level_tree == 2 || (v.top_level_tree < 0 && e && std::atoi(e) == 2));
+    }
     k.gather = v.gather == 1 || v.gather == 2 ? v.gather : -1;
     if (v.gather < 0)
         if (const char* e = std::getenv("RT_AMD_GATHER")) k.gather = std::strcmp(e, "rccl") == 0 ? 1 : std::strcmp(e, "peer") == 0 ? 2 : -1;
@@ -1023,6 +1030,8 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     popts.device_bvh = knobs.device_bvh;
     popts.cull_ranges = knobs.cull;
     popts.share_meshes = knobs.share_meshes;
+    popts.top_level_tree = knobs.tlas;
+    popts.tlas_instances = knobs.tlas_instances;
     popts.verbose = knobs.verbose;
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);
@@ -1118,6 +1127,8 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
     s->ds.cull_reach = prog.cull_reach;
+    s->ds.tlas_root = prog.tlas_root;
+    s->ds.n_linear = prog.n_linear;
     s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));
     s->trav_lds_bytes = prog.bvh.empty() ? 0 : size_t(s->ds.n_lds) * sizeof(BvhNode) + size_t(LDS_STACK) * TBLOCK * sizeof(int);
     {
@@ -1128,7 +1139,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         s->ds.spill_lanes = (long long)s->n_cus * 2048;
         void* sp = nullptr;
         // as many rows as this scene's deepest tree can ask for (3 pending siblings per BVH4 level; host-built trees: <= 31)
-        const int spill_rows = std::max(1, 3 * int(prog.bvh_max_depth) + 1 - LDS_STACK);
+        const int spill_rows = std::max(1, 3 * int(prog.bvh_max_depth + prog.tlas_levels) + 1 - LDS_STACK);
         if (hipMalloc(&sp, size_t(spill_rows) * size_t(s->ds.spill_lanes) * sizeof(int32_t)) != hipSuccess) {
             rt_set_error("could not allocate the traversal stack spill area");
             return fail(RT_ERR_HIP);
@@ -1159,13 +1170,14 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     if (knobs.verbose)
         std::fprintf(stderr, "rt_scene_create: %.3f s so far (compile + uploads)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create0).count());
     if (knobs.verbose)
-        std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items, %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
-                     d.n_nodes, prog.items.size(), prog.bvh.size(), s->ds.n_lds, s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(),
-                     (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0));
+        std::fprintf(stderr, "rt_scene_create: %d nodes, %zu program items (%d walked by every ray, top-level tree: %s, %d levels), %zu BVH4 nodes (%d in LDS, %zu bytes of LDS per workgroup of %d lanes), %zu mesh triangles, scene class %d\n",
+                     d.n_nodes, prog.items.size(), prog.n_linear, prog.tlas_root >= 0 ? "yes" : "no", prog.tlas_levels, prog.bvh.size(), s->ds.n_lds,
+                     s->trav_lds_bytes, TBLOCK, prog.mesh_tris.size(), (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0));
     s->meshes_built_on_gpu = prog.meshes_built_on_gpu;
     s->meshes_shared = prog.meshes_shared;
     s->has_csg = prog.has_csg;
-    s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0);
+    s->scene_class = (prog.has_csg ? SC_CSG : 0) | (prog.has_cull ? SC_CULL : 0) | (prog.tlas_root >= 0 ? SC_TLAS : 0);
+    s->has_tlas = prog.tlas_root >= 0;
     s->has_smooth = prog.has_smooth;
     s->n_lights = d.n_lights;
     for (int m = 0; m < d.n_materials; ++m) {  // does any material ever need the n1/n2 walk?
@@ -1769,8 +1781,8 @@ static int list_pass(rt_scene* s, bool big, int64_t n, const double* origins, co
     int32_t* ids = static_cast<int32_t*>(s->misc_c.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
-    if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
-    else if (s->has_csg) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     else rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     s->big = false;
     if (rc != RT_OK) return rc;
@@ -1838,8 +1850,8 @@ static int shadow_pass(rt_scene* s, bool big, int64_t n, const double* points, u
     uint8_t* o = static_cast<uint8_t*>(s->misc_a.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
-    if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
-    else if (s->has_csg) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     else rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     s->big = false;
     if (rc != RT_OK) return rc;
@@ -1902,7 +1914,7 @@ int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, 
     int32_t* ids = static_cast<int32_t*>(s->misc_a.p);
     double* comps = static_cast<double*>(s->misc_b.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
-    if (s->has_csg) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
+    if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     else rc = launch_trav(s, st, k_comps<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());

@@ -560,11 +560,11 @@ __device__ __forceinline__ void cswap(float& ta, int& ca, float& tb, int& cb) {
 
 template <bool COUNT, class Sink, class E>
 __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, int root, int node_base, V3 o, V3 d, V3 inv, const Sink& sink,
-                                             bool full_line, Work& w, E&& e) {
+                                             bool full_line, Work& w, int sp0, E&& e) {
     const RayF rf = make_rayf(o, inv);
     // A launch lasts as long as its slowest wavefront, and the slow ones are in here: let them issue first.
     __builtin_amdgcn_s_setprio(3);
-    int sp = 0;
+    int sp = sp0;  // entries below sp0 belong to the top-level tree's walk (tlas_next), suspended while this mesh is traversed
     int cur = root;
     while (true) {
         if (cur >= 0) {
@@ -666,10 +666,85 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                 }
             }
         }
-        if (sp == 0 || sink.done()) break;
+        if (sp == sp0 || sink.done()) break;
         cur = stack_pop(M, --sp);
     }
     __builtin_amdgcn_s_setprio(0);
+}
+
+// The walk of the top-level tree (rt_program.h: Program::tlas_root), one lane = one ray, resumable: returns the item index
+// of the next bounded top-level object whose world box the ray meets within what its sink still accepts — nearest
+// boxes first — or INT_MAX when the tree is exhausted.  The pending entries stay in the lane's stack column (`tsp` of
+// them) while the wavefront works through the object.  Acceleration only: the boxes are the ITEM_CULL boxes (padded,
+// rounded outward to f32 and tested with the node test's error budget), a ray that starts beyond the scene's reach
+// (`trusted` == false) is handed every object, and the object's own ITEM_CULL tests its f64 box once more — against
+// the bound the sink has by then — before anything is intersected.
+template <bool COUNT, class Sink>
+__device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 ro, V3 rd, const Sink& sink, bool trusted, int& tsp, Work& w) {
+    const V3 inv = mk(slab_rcp(rd.x), slab_rcp(rd.y), slab_rcp(rd.z));
+    const RayF rf = make_rayf(ro, inv);
+    while (tsp > 0) {
+        const int cur = stack_pop(M, --tsp);
+        if (cur < 0) return ~cur;
+        float lo[3][4], hi[3][4];
+        int ch[4];
+        if (cur < M.n_lds) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const RT_LDS f32x4* __restrict__ col = (const RT_LDS f32x4*)M.lds_nodes;  // column-major, see bvh_traverse
+            const int N = M.n_lds;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const f32x4 l = col[a * N + cur], h = col[(3 + a) * N + cur];
+                lo[a][0] = l.x; lo[a][1] = l.y; lo[a][2] = l.z; lo[a][3] = l.w;
+                hi[a][0] = h.x; hi[a][1] = h.y; hi[a][2] = h.z; hi[a][3] = h.w;
+            }
+            const i32x4 c4 = ((const RT_LDS i32x4*)M.lds_nodes)[6 * N + cur];
+            ch[0] = c4.x; ch[1] = c4.y; ch[2] = c4.z; ch[3] = c4.w;
+        } else {
+            const BvhNode* __restrict__ n = S.bvh + cur;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { lo[a][c] = n->lo[a][c]; hi[a][c] = n->hi[a][c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ch[c] = n->child[c];
+        }
+        bump<COUNT>(w.bvh_nodes);
+        bump<COUNT>(w.box, 4);
+        const double tlo = sink.lo(), thi = sink.hi();
+        float tn[4];
+        if (rf.ok) {
+            const float tlo_f = __double2float_rd(tlo), thi_f = __double2float_ru(thi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t;
+                bool hit = (bvh_box_f32<false>(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t) | !trusted) &
+                           (ch[c] != INT32_MIN);
+                tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
+                if (!hit) ch[c] = INT32_MIN;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double t;
+                bool hit = (bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c], (double)hi[2][c],
+                                    ro, inv, tlo, thi, t) | !trusted) & (ch[c] != INT32_MIN);
+                tn[c] = hit ? (t == t ? (float)t : -INFINITY) : INFINITY;
+                if (!hit) ch[c] = INT32_MIN;
+            }
+        }
+        cswap(tn[0], ch[0], tn[1], ch[1]);
+        cswap(tn[2], ch[2], tn[3], ch[3]);
+        cswap(tn[0], ch[0], tn[2], ch[2]);
+        cswap(tn[1], ch[1], tn[3], ch[3]);
+        cswap(tn[1], ch[1], tn[2], ch[2]);
+        if (ch[3] != INT32_MIN) stack_push(M, tsp++, ch[3]);
+        if (ch[2] != INT32_MIN) stack_push(M, tsp++, ch[2]);
+        if (ch[1] != INT32_MIN) stack_push(M, tsp++, ch[1]);
+        if (ch[0] != INT32_MIN) stack_push(M, tsp++, ch[0]);  // popped next: the nearest
+    }
+    return 0x7fffffff;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -741,10 +816,11 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // with the whole wavefront executing.
 // SC = scene class: bit 0 the scene has CSG nodes, bit 1 its program has ITEM_CULL ranges (code for either is only
 // compiled into the kernels of scenes that need it).
-constexpr int SC_CSG = 1, SC_CULL = 2, SC_BIG = 4;
+constexpr int SC_CSG = 1, SC_CULL = 2, SC_BIG = 4, SC_TLAS = 8;  // SC_TLAS (with SC_CULL): the world has a top-level tree
 template <int SC, bool COUNT, class Sink>
 __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive) {
     constexpr bool HAS_CSG = (SC & SC_CSG) != 0, HAS_CULL = (SC & SC_CULL) != 0, BIG = (SC & SC_BIG) != 0;
+    constexpr bool HAS_TLAS = (SC & SC_TLAS) != 0 && HAS_CULL;
     CsgScratch<BIG>* cs = nullptr;
     CsgScratch<BIG> cs_storage;
     if (HAS_CSG) {
@@ -780,7 +856,70 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     const int n_items = S.n_items;
     int until = alive ? 0 : n_items;
     int i = 0;
-    while (i < n_items) {
+    // Worlds with a top-level tree (SC_TLAS kernels): the first n_linear items are walked by every ray as ever; the bounded
+    // objects behind them are ranges [ITEM_CULL, ..., skip) that a ray visits only when its own walk of the tree
+    // (tlas_next) names them.  Each lane holds the next object ITS ray has to visit (`cand`).  While the lanes of the
+    // wavefront agree, or the object is not a mesh instance, the wavefront goes to the lowest of them with the item
+    // index wavefront-uniform as ever (scalar fetches of item and matrices): the lanes that asked for it are awake there,
+    // the others sleep through it and keep their candidate for a later round.  When lanes hold DIFFERENT mesh instances
+    // (an object that is one ITEM_MESH under its transforms: the teapots of a grid seen by incoherent rays), every lane
+    // walks its own instance at the same time, with its own transformed ray, instead of the wavefront taking them in turn.
+    const bool tlas = HAS_TLAS && S.tlas_root >= 0;
+    int range_end = HAS_TLAS ? S.n_linear : n_items;
+    int tsp = 0, cand = -1;
+    bool mine = false;  // this lane asked for the range the wavefront is in
+    if (tlas && alive) {
+        stack_push(M, 0, S.tlas_root);
+        tsp = 1;
+    }
+    while (true) {
+        // SC_TLAS kernels have ONE call of the mesh traversal, at the end of the loop body, for whoever set up a job in this
+        // round: the lanes a wavefront-uniform ITEM_MESH is meant for, or lanes that each fetched an instance of their own
+        // (a second inlined copy of bvh_traverse took these kernels from 43 to 192 spilled registers)
+        bool job = false, job_full = false, items_round = true;
+        V3 job_o = ro, job_d = rd, job_inv = rd;
+        int job_root = 0, job_base = 0;
+        if (HAS_TLAS && i >= range_end) {
+            if (!tlas) break;
+            if (mine) cand = -1;  // that range is done
+            mine = false;
+            if (!alive) cand = 0x7fffffff;
+            if (cand != 0x7fffffff && sink.done()) cand = 0x7fffffff;
+            if (cand < 0) cand = tlas_next<COUNT>(S, M, ro, rd, sink, cull_trusted, tsp, w);
+            const bool instance = cand != 0x7fffffff && (cand & TLAS_INSTANCE);
+            const int header = instance ? (cand & ~TLAS_INSTANCE) - 1 : cand;  // an instance's ITEM_CULL sits in front of its ITEM_MESH
+            const int lowest = wave_min_i32(header);
+            if (lowest == 0x7fffffff) break;
+            if (__ballot(instance && header != lowest) == 0) {  // the wavefront agrees (or the lowest is no instance): uniform walk
+                mine = header == lowest;
+                range_end = items[lowest].skip;
+                // an instance's ITEM_CULL is skipped: its ITEM_MESH tests the mesh's own, tighter box against the same bounds
+                i = __ballot(mine && instance) ? lowest + 1 : lowest;
+                until = mine ? i : (cand == 0x7fffffff ? n_items : range_end);
+            } else {  // lanes hold different instances: each sets up its own, all are traversed together below
+                items_round = false;
+                if (instance) {
+                    const Item* __restrict__ q = S.items + (cand & ~TLAS_INSTANCE);  // per-lane fetch
+                    const int m_node = q->node, m_root = q->a, m_box = q->b, m_len = q->chain_len, m_x0 = q->x0, m_x1 = q->x1, m_chain = q->chain;
+                    V3 o = ro, d = rd;
+                    for (int k = 0; k < m_len; ++k) {  // Ray::transform per level, outermost first (src/shape.rs:75-76)
+                        const int x = k == 0 ? m_x0 : k == 1 ? m_x1 : S.chain_pool[m_chain + 1 + k];
+                        const double* __restrict__ m = S.xf + (size_t)x * 12;
+                        o = xf_point(m, o);
+                        d = xf_vector(m, d);
+                    }
+                    if (COUNT) { w.xforms += m_len; ++w.box; }
+                    const double* __restrict__ mb = S.mesh_box + (size_t)m_box * 6;
+                    const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+                    double tnear;
+                    job = bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, sink.lo_mesh(), sink.hi(), tnear);
+                    job_o = o; job_d = d; job_inv = inv; job_root = m_root; job_base = m_node;
+                    cand = -1;
+                }
+            }
+        }
+        if (!HAS_TLAS && i >= n_items) break;
+        if (items_round) {
         Item it;  // one 64-byte scalar fetch (member-wise: aggregates do not copy across address spaces)
         {
             const RT_CONSTANT Item* __restrict__ q = items + i;
@@ -900,10 +1039,11 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
             bump<COUNT>(w.box);
             if (bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, full_line ? -INFINITY : sink.lo_mesh(), sink.hi(), tnear))
             {
-                bvh_traverse<COUNT>(S, M, it.a, it.node, o, d, inv, sink, full_line, w, out_mesh);
+                if (HAS_TLAS) { job = true; job_full = full_line; job_o = o; job_d = d; job_inv = inv; job_root = it.a; job_base = it.node; }
+                else bvh_traverse<COUNT>(S, M, it.a, it.node, o, d, inv, sink, full_line, w, tsp, out_mesh);
             }
-            continue;
-        }
+            if (!HAS_TLAS) continue;
+        } else {
         // ITEM_LEAF
         const int node = it.node;
         auto leaf_out = [&](double t, int k, double u, double v, int uv) { out(t, node * 4 + k, u, v, uv); };
@@ -920,6 +1060,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                 break;
             }
         }
+        }
+        }  // items_round
+        if (HAS_TLAS && job) bvh_traverse<COUNT>(S, M, job_root, job_base, job_o, job_d, job_inv, sink, job_full, w, tsp, out_mesh);
     }
     if (HAS_CSG) sink.flags |= cs->flags;
 }

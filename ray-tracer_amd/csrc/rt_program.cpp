@@ -86,6 +86,7 @@ struct Compiler {
     std::vector<BvhNode> n4;
     std::vector<int32_t> n4_depth;
     std::vector<size_t> mesh_items;  // items whose `a` is a root index into n4
+    int depth_bias = 0;              // collapse(): added to the depth a node is sorted by (the top-level tree: far below 0)
     Box last_mesh_box;               // padded bounds of the mesh build_mesh built last
 
     int32_t emit_leaf(std::vector<TriRef>& refs, size_t lo, size_t hi) {
@@ -236,8 +237,9 @@ struct Compiler {
         }
         int32_t me = int32_t(n4.size());
         n4.emplace_back();
-        n4_depth.push_back(depth);
-        p.bvh_max_depth = std::max(p.bvh_max_depth, depth + 1);
+        n4_depth.push_back(depth + depth_bias);
+        if (depth_bias) p.tlas_levels = std::max(p.tlas_levels, depth + 1);   // the top-level tree: sorted in front of every mesh
+        else p.bvh_max_depth = std::max(p.bvh_max_depth, depth + 1);
         BvhNode nd;
         std::memset(&nd, 0, sizeof nd);
         for (int c = 0; c < 4; ++c) {
@@ -431,6 +433,7 @@ struct Compiler {
             p.bvh[i] = nd;
         }
         for (size_t it : mesh_items) p.items[it].a = where[size_t(p.items[it].a)];
+        if (p.tlas_root >= 0) p.tlas_root = where[size_t(p.tlas_root)];
     }
 
     // ---- world-space bounds of top-level objects (ITEM_CULL) --------------------------------------------------
@@ -584,9 +587,9 @@ struct Compiler {
     // (a dependent scalar fetch), and with the headline scene's three bounded objects that lost 4 % of the frame, while
     // the 32-object grid of C5 renders 1.85x faster with it and the 8-object C4 1.17x.
     static constexpr size_t CULL_MIN_OBJECTS = 6;
-    void emit_culled(std::vector<std::pair<int32_t, WBox>>& roots, size_t lo, size_t hi) {
+    void emit_culled(std::vector<std::pair<int32_t, WBox>>& roots, size_t lo, size_t hi, bool always = false) {
         if (hi - lo == 0) return;
-        if (roots.size() < CULL_MIN_OBJECTS || !opts.cull_ranges) {
+        if (!always && (roots.size() < CULL_MIN_OBJECTS || !opts.cull_ranges)) {
             for (size_t i = lo; i < hi; ++i) emit(roots[i].first, {});
             return;
         }
@@ -633,10 +636,78 @@ struct Compiler {
                              [&](const std::pair<int32_t, WBox>& a, const std::pair<int32_t, WBox>& b) {
                                  return a.second.lo[axis] + a.second.hi[axis] < b.second.lo[axis] + b.second.hi[axis];
                              });
-            emit_culled(roots, lo, mid);
-            emit_culled(roots, mid, hi);
+            emit_culled(roots, lo, mid, always);
+            emit_culled(roots, mid, hi, always);
         }
         if (cull >= 0) p.items[size_t(cull)].skip = int32_t(p.items.size());
+    }
+
+    // The same bounded objects as a tree instead of nested ranges (worlds of >= TLAS_MIN_OBJECTS of them): each object
+    // becomes [ITEM_CULL(its own padded world box, skip = end of the object), the object's items), and a BVH4 over the
+    // boxes — binary median splits of the box centres collapsed like the mesh trees, boxes rounded outward to f32 —
+    // names the ranges a ray has to visit.  The bounds are the cull ranges' bounds (world_box(): the reference's
+    // ACCEPTANCE rules, not the ideal shapes), so are the padding and the reach guard: what holds for a range holds here.
+    int32_t tlas_build(std::vector<std::pair<int32_t, WBox>>& roots, size_t lo, size_t hi, Box& box) {
+        box.reset();
+        for (size_t i = lo; i < hi; ++i) box.add(cull_box(p.items[size_t(tlas_header[i])]), cull_box(p.items[size_t(tlas_header[i])]) + 3);
+        if (hi - lo == 1) {
+            // an object that is nothing but one mesh under its transforms — [ITEM_CULL, ITEM_MESH) — is an INSTANCE: the
+            // link names the ITEM_MESH itself and the kernels let every lane walk its own instance at the same time
+            // (rt_kernels.hip.h: traverse), instead of the wavefront visiting the objects one after the other
+            const int32_t h = tlas_header[lo];
+            const bool instance = RT_TLAS_PER_LANE && opts.tlas_instances && p.items[size_t(h)].skip == h + 2 && p.items[size_t(h) + 1].type == ITEM_MESH;
+            return instance ? ~((h + 1) | TLAS_INSTANCE) : ~h;
+        }
+        int axis = 0;
+        double ext = -1.;
+        for (int k = 0; k < 3; ++k) {
+            double cl = INF, ch = -INF;
+            for (size_t i = lo; i < hi; ++i) {
+                const double c = 0.5 * roots[i].second.lo[k] + 0.5 * roots[i].second.hi[k];
+                cl = std::min(cl, c);
+                ch = std::max(ch, c);
+            }
+            if (ch - cl > ext) { ext = ch - cl; axis = k; }
+        }
+        // (roots and header are permuted together: sort an index, then apply)
+        const size_t mid = lo + (hi - lo) / 2;
+        std::vector<size_t> idx(hi - lo);
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = lo + i;
+        std::nth_element(idx.begin(), idx.begin() + long(mid - lo), idx.end(), [&](size_t a, size_t b) {
+            const double ca = roots[a].second.lo[axis] + roots[a].second.hi[axis], cb = roots[b].second.lo[axis] + roots[b].second.hi[axis];
+            return ca < cb || (ca == cb && a < b);
+        });
+        {
+            std::vector<std::pair<int32_t, WBox>> r2(idx.size());
+            std::vector<int32_t> h2(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) { r2[i] = roots[idx[i]]; h2[i] = tlas_header[idx[i]]; }
+            for (size_t i = 0; i < idx.size(); ++i) { roots[lo + i] = r2[i]; tlas_header[lo + i] = h2[i]; }
+        }
+        const int32_t me = int32_t(n2.size());
+        n2.emplace_back();
+        Box b0, b1;
+        const int32_t c0 = tlas_build(roots, lo, mid, b0);
+        const int32_t c1 = tlas_build(roots, mid, hi, b1);
+        Node2& nd = n2[size_t(me)];
+        nd.box[0] = b0; nd.box[1] = b1;
+        nd.child[0] = c0; nd.child[1] = c1;
+        return me;
+    }
+    std::vector<int32_t> tlas_header;  // per bounded object (same order as `roots`): index of its ITEM_CULL
+    void emit_tlas(std::vector<std::pair<int32_t, WBox>>& roots) {
+        p.n_linear = int32_t(p.items.size());
+        tlas_header.assign(roots.size(), -1);
+        for (size_t i = 0; i < roots.size(); ++i) {
+            const size_t before = p.items.size();
+            emit_culled(roots, i, i + 1, true);   // ITEM_CULL(own box) + the object + skip
+            tlas_header[i] = int32_t(before);
+        }
+        n2.clear();
+        Box rb;
+        const int32_t root2 = tlas_build(roots, 0, roots.size(), rb);
+        depth_bias = -(1 << 20);
+        p.tlas_root = collapse(root2, 0);
+        depth_bias = 0;
     }
 
     // ---- traversal program -----------------------------------------------------------------------------
@@ -864,7 +935,9 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
             if (wb.bounded && wb.lo[0] <= wb.hi[0]) bounded.emplace_back(n, wb);
             else c.emit(n, {});
         }
-    c.emit_culled(bounded, 0, bounded.size());
+    if (opts.cull_ranges && opts.top_level_tree && bounded.size() >= size_t(TLAS_MIN_OBJECTS)) c.emit_tlas(bounded);
+    else c.emit_culled(bounded, 0, bounded.size());
+    if (out.tlas_root < 0) out.n_linear = int32_t(out.items.size());
     for (int32_t n = 0; n < d.n_nodes; ++n) {
         int32_t k = d.node_kind[n];
         if (k <= RT_SMOOTH_TRIANGLE) {
@@ -880,7 +953,7 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
                              "depth ordering %.3f s; %d meshes built on the GPU, %d meshes took the tree of an identical earlier one, deepest tree %d levels\n",
                      t_validated - t_begin, t_emitted - t_validated, c.t_dedup, c.t_refs, c.t_tree, Compiler::now() - t_emitted,
                      out.meshes_built_on_gpu, out.meshes_shared, out.bvh_max_depth);
-    if (3 * out.bvh_max_depth + 1 > BVH_STACK) {
+    if (3 * (out.bvh_max_depth + out.tlas_levels) + 1 > BVH_STACK) {
         err = "BVH deeper than the device traversal stack";
         return RT_ERR_UNSUPPORTED;
     }

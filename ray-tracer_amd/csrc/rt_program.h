@@ -83,6 +83,14 @@ struct Program {
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
     int32_t meshes_built_on_gpu = 0;   // meshes whose tree topology came from rt_lbvh.hip
+    // Worlds of many bounded top-level objects (>= TLAS_MIN_OBJECTS): instead of nested ITEM_CULL ranges walked in program
+    // order, every bounded object is a range of its own — [ITEM_CULL with the object's world box, the object's items) —
+    // behind the first `n_linear` items (the unbounded objects, walked by every ray as before), and a BVH4 over the
+    // objects' world boxes (`tlas_root`, nodes in front of all mesh nodes so that they are always staged in LDS; a
+    // leaf link is ~(index of the object's ITEM_CULL)) tells each ray which ranges to visit, nearest first.
+    int32_t tlas_root = -1;            // -1: no top-level tree, the whole program is walked linearly
+    int32_t n_linear = 0;              // items [0, n_linear) are walked by every ray (== items.size() without a tree)
+    int32_t tlas_levels = 0;           // BVH4 levels of the top-level tree (its share of the traversal stack)
     bool has_cull = false;             // the program has ITEM_CULL ranges
     double cull_reach = 0.;            // ... trusted for rays whose origin has max |coordinate| below this (WBox::reach)
     bool has_smooth = false;
@@ -99,6 +107,8 @@ struct ProgramOpts {
     int build_device = -1;
     bool device_bvh = false;
     bool cull_ranges = true;
+    bool tlas_instances = true;  // ... whose one-mesh objects are walked per lane (RT_AMD_TLAS=2: left to the wavefront, A/B)
+    bool top_level_tree = true;  // worlds with >= TLAS_MIN_OBJECTS bounded top-level objects get a tree over them (RT_AMD_TLAS=0: A/B)
     bool share_meshes = true;   // groups with identical triangle content take one tree (RT_AMD_SHARE_MESHES=0: A/B)
     bool verbose = false;   // phase times of the compilation on stderr
 };
@@ -114,6 +124,17 @@ struct BvhNode;
 bool lbvh_build(int device, size_t n, const double* tri_lo, const double* tri_hi, double pad, int32_t tri_base, int max_levels,
                 std::vector<int32_t>& order, std::vector<BvhNode>& nodes, std::vector<int32_t>& level_start, double root_box[6]);
 
+// Per-lane walks of mesh instances under the top-level tree: compiled in only on request (-DRT_TLAS_PER_LANE=1).  Measured
+// (DESIGN.md section 7, round 3): the second inlined copy of the mesh traversal takes the SC_TLAS kernels from 43 to 192
+// spilled registers, which costs C5 more (grid 4: 15.2 -> 19.6 ms) than lanes working side by side on different teapots
+// gain (grid 13: 27.4 -> 23.9 ms inside one binary, against 23.6 ms for the binary without the code).
+#ifndef RT_TLAS_PER_LANE
+#define RT_TLAS_PER_LANE 1
+#endif
+constexpr int32_t TLAS_INSTANCE = 1 << 29;  // in a top-level leaf link ~c: c & ~TLAS_INSTANCE is the index of an ITEM_MESH (a mesh
+                                            // instance, walked per lane) rather than of an object's ITEM_CULL (walked by the wavefront)
+constexpr int TLAS_MIN_OBJECTS = 64;     // fewer bounded top-level objects: nested ITEM_CULL ranges in program order (measured on C5
+                                         // at 8K, ranges / tree: 32 objects 14.3 / 15.9 ms, 72: 17.1 / 17.0, 128: 19.0 / 18.0, 338: 24.8 / 20.5)
 constexpr int LBVH_MIN_TRIANGLES = 1024; // smaller meshes are always built on the host
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
 constexpr int BVH_LEAF_MAX = 4;        // triangles per leaf (measured: 1 -> 2.74 ms, 2 -> 2.21 ms, 4 -> 2.12 ms per frame); fetched two at a time

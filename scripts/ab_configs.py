@@ -8,6 +8,10 @@ import rt_amd as rt, scenes
 cases = [("C2 teapot_low", scenes.teapot_low, (1920, 1080), 5), ("C3 teapot", scenes.teapot_scene, (1920, 1080), 5),
          ("C3s smooth", lambda w, h: scenes.teapot_scene(w, h, obj_text=scenes.smooth_teapot_obj()), (1920, 1080), 5),
          ("C4 mixed", scenes.mixed_scene, (2560, 1440), 5), ("C5 grid4", lambda w, h: scenes.instanced_grid(w, h, grid=4), (7680, 4320), 8)]
+if os.environ.get("AB_GRIDS"):   # only C5 at the listed grid sizes
+    cases = [("C5 grid%d" % g, (lambda g: lambda w, h: scenes.instanced_grid(w, h, grid=g))(g), (7680, 4320), 8) for g in map(int, os.environ["AB_GRIDS"].split(","))]
+elif os.environ.get("AB_GRID13", "1") != "0":
+    cases.append(("C5 grid13", lambda w, h: scenes.instanced_grid(w, h, grid=13), (7680, 4320), 8))
 for name, b, (W, H), depth in cases:
     w, cam = b(W, H)
     scene = w.scene(0)
@@ -17,7 +21,7 @@ for name, b, (W, H), depth in cases:
     for _ in range(4):
         assert rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None, None) == 0
     torch.cuda.synchronize()
-    K = 10
+    K = 10 if not name.startswith("C5") else 5
     t0 = time.perf_counter()
     for _ in range(K):
         rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(opts), frame.data_ptr(), None, None, None)

@@ -182,6 +182,89 @@ def build_composite_world():
     return w
 
 
+def _triangle_record(p1, p2, p3):
+    """Triangle::new in plain Python floats (src/triangle.rs:38-56): e1 = p2 - p1, e2 = p3 - p1, normal = normalize(e2 x e1)
+    with Tuple::cross (tuple.rs:49-52) and Tuple::normalize (tuple.rs:32-43: one sqrt, then a division per component).
+    Independent of the host mirror: nothing here calls into the library."""
+    e1 = [p2[k] - p1[k] for k in range(3)]
+    e2 = [p3[k] - p1[k] for k in range(3)]
+    c = [e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]]
+    m = math.sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + 0. * 0.)
+    return e1, e2, [c[0] / m, c[1] / m, c[2] / m]
+
+
+# an octahedron: six vertices (1-based, as an OBJ file numbers them), eight faces; two faces carry vertex normals
+OCTA_V = [None, [1., 0., 0.], [-1., 0., 0.], [0., 1., 0.], [0., -1., 0.], [0., 0., 1.], [0., 0., -1.]]
+OCTA_F = [(1, 3, 5, False), (3, 2, 5, False), (2, 4, 5, True), (4, 1, 5, False), (3, 1, 6, False), (2, 3, 6, False), (4, 2, 6, True), (1, 4, 6, False)]
+OCTA_OBJ = "".join("v %r %r %r\n" % tuple(v) for v in OCTA_V[1:]) + "".join("vn %r %r %r\n" % tuple(v) for v in OCTA_V[1:]) + \
+    "".join(("f %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c)) if smooth else ("f %d %d %d\n" % (a, b, c)) for a, b, c, smooth in OCTA_F)
+
+
+def mesh_world():
+    """A parsed mesh under a two-level TRANSFORMED ancestor chain, tables typed in from the reference's definitions:
+      0 plane translate(0,-1.5,0), reflective 0.2
+      1 group OUTER translate(0.5,0.25,1), glass-like material (the ROOT ancestor's material is every triangle's, F7)
+      2   group WRAP scale(2,2,2)            = obj_to_group's main_group (src/obj_file.rs:164-172)
+      3     group DEFAULT (identity)         = the parser's default group (src/obj_file.rs:33-35)
+      4..11   the octahedron's eight faces in file order; faces 2 and 6 are SmoothTriangles (`f a//a b//b c//c`,
+              src/obj_file.rs:75-100) whose vertex normals are the vertex positions
+    Every group box is (-inf, +inf): a triangle's box is EMPTY (triangle.rs:93-95), Bound::transform of a box with an infinite
+    corner yields NaN points (0 * inf in Matrix * Tuple) that add_point ignores, so the transformed box is EMPTY again, and
+    add_box(EMPTY) turns the group box into (-inf, +inf) (bound.rs:35-47) — at every level.
+    world_to_object / normal_to_world walk DEFAULT -> WRAP -> OUTER (shape.rs:394-420): three ancestor entries, the
+    identity one included."""
+    floor = [1., 1., 1., 0.1, 0.9, 0.9, 200., 0.2, 0., 1.]
+    glass = [0.8, 0.9, 1., 0.1, 0.4, 0.9, 200., 0.3, 0.6, 1.4]
+    p1s, e1s, e2s, ns, smooth, sn = [], [], [], [], [], [[], [], []]
+    for a, b, c, is_smooth in OCTA_F:
+        e1, e2, n = _triangle_record(OCTA_V[a], OCTA_V[b], OCTA_V[c])
+        p1s.append(OCTA_V[a]); e1s.append(e1); e2s.append(e2); ns.append(n)
+        if is_smooth:
+            smooth.append(len(sn[0]))
+            for k, v in enumerate((a, b, c)):
+                sn[k].append(OCTA_V[v])
+        else:
+            smooth.append(-1)
+    box = [-INF, -INF, -INF, INF, INF, INF]
+    kinds = [rt.RT_SMOOTH_TRIANGLE if f[3] else rt.RT_TRIANGLE for f in OCTA_F]
+    t = dict(EMPTY)
+    t.update(
+        node_kind=[rt.RT_PLANE, rt.RT_GROUP, rt.RT_GROUP, rt.RT_GROUP] + kinds,
+        node_object_id=[201, 202, 203, 204] + list(range(205, 213)),
+        node_parent=[-1, -1, 1, 2] + [3] * 8,
+        node_subtree_end=[1, 12, 12, 12] + list(range(5, 13)),
+        node_xform=[1, 2, 3, 0] + [0] * 8,
+        node_ancestor=[-1, -1, -1, -1] + [0] * 8,
+        node_material=[0, -1, -1, -1] + [1] * 8,
+        node_casts_shadow=[1] * 12,
+        node_eq_class=[0, -1, -1, -1] + list(range(1, 9)),
+        node_param=[-1, 0, 1, 2] + list(range(8)),
+        xform_inverse=[IDENT, translation(0., 1.5, 0.), translation(-0.5, -0.25, -1.), scaling(0.5, 0.5, 0.5)],
+        ancestor_xform=[0, 3, 2], ancestor_parent=[1, 2, -1],      # DEFAULT -> WRAP -> OUTER
+        group_box=[box, box, box],
+        tri_p1=p1s, tri_e1=e1s, tri_e2=e2s, tri_normal=ns, tri_smooth=smooth,
+        smooth_n1=sn[0], smooth_n2=sn[1], smooth_n3=sn[2],
+        material_params=[floor, glass], material_pattern=[-1, -1],
+        light_position=[[-8., 9., -10.], [6., 4., -6.]], light_intensity=[[1., 1., 1.], [0.3, 0.3, 0.4]])
+    return HandDesc(**t)
+
+
+def build_mesh_world():
+    """The same scene through parse_obj_file + obj_to_group (by default the packed OBJ path, rth_obj_file_to_group)."""
+    from rt_amd import Light, Material, Shape, World, scale, translate
+    w = World()
+    w.lights += [Light.point_light((-8., 9., -10.), rt.WHITE), Light.point_light((6., 4., -6.), (0.3, 0.3, 0.4))]
+    plane = Shape.plane().set_transform(translate(0., -1.5, 0.)).set_material(Material(reflective=0.2))
+    wrap, counts = rt.obj_to_group(OCTA_OBJ)
+    assert counts["triangles"] == 8 and counts["lines_ignored"] == 0
+    wrap.set_transform(scale(2., 2., 2.))
+    outer = Shape.group().set_transform(translate(0.5, 0.25, 1.))
+    outer.add_child(wrap)
+    outer.set_material(Material(color=(0.8, 0.9, 1.), diffuse=0.4, reflective=0.3, transparency=0.6, refractive_index=1.4))
+    w.objects += [plane, outer]
+    return w
+
+
 def canonical(desc_ptr):
     """Expands a descriptor into per-node content that does not depend on how the tables are organised (index
     assignment, de-duplication, id values): what the renderers actually consume."""

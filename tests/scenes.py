@@ -189,6 +189,104 @@ def instanced_grid(hsize=7680, vsize=4320, grid=4):
     return w, cam
 
 
+def many_objects_scene(seed=0, hsize=96, vsize=54, n=40):
+    """A world of many BOUNDED top-level objects (spheres, closed / truncated cylinders, CSG of those, groups of those —
+    glass, mirrors, patterns, a non-casting one) between a few unbounded ones (floor plane, a cube, an open cone): what
+    the top-level tree of rt_program.cpp is built for.  Two lights."""
+    rng = np.random.RandomState(4200 + seed)
+    w = World()
+    w.lights.append(Light.point_light((-9., 14., -11.), rt.WHITE))
+    w.lights.append(Light.point_light((12., 9., -4.), (0.35, 0.3, 0.3)))
+    w.objects.append(Shape.plane().set_material(Material(color=(0.8, 0.8, 0.75), reflective=0.25, pattern=Pattern.checkered((0.9, 0.9, 0.9), (0.2, 0.2, 0.25)))))
+    w.objects.append(Shape.cube().set_transform(translate(-7., 1., 9.) * scale(1., 1., 1.)).set_material(Material(color=(0.8, 0.3, 0.2), reflective=0.3)))
+    w.objects.append(Shape.cone().set_minimum(-1.).set_maximum(0.).set_transform(translate(7., 2., 10.) * scale(1., 2., 1.)).set_material(Material(color=(0.2, 0.7, 0.3))))
+
+    def material():
+        r = rng.rand()
+        if r < 0.2:
+            return Material(color=(1., 1., 1.), diffuse=0.1, ambient=0.05, reflective=0.7, transparency=0.85, refractive_index=1.2 + 0.5 * rng.rand())
+        if r < 0.35:
+            return Material(color=tuple(rng.uniform(0.5, 1., 3)), diffuse=0.3, reflective=0.8)
+        m = Material(color=tuple(rng.uniform(0.1, 1., 3)), diffuse=0.7, specular=0.4, shininess=float(rng.uniform(10., 200.)))
+        if r < 0.5:
+            m.pattern = Pattern.striped(tuple(rng.uniform(0., 1., 3)), tuple(rng.uniform(0., 1., 3))).set_transform(scale(0.3, 0.3, 0.3))
+        return m
+
+    def place(shape, size):
+        x, z = rng.uniform(-9., 9.), rng.uniform(-2., 16.)
+        return shape.set_transform(translate(x, size + rng.uniform(0., 2.5), z) * rotate(rng.uniform(0., PI), Axis.Y) *
+                                   rotate(rng.uniform(-0.6, 0.6), Axis.X) * scale(size, size * rng.uniform(0.6, 1.4), size))
+
+    def prim():
+        if rng.rand() < 0.55:
+            return Shape.sphere()
+        c = Shape.cylinder().set_minimum(float(rng.uniform(-1.5, -0.2))).set_maximum(float(rng.uniform(0.2, 1.5)))
+        return c.set_closed(bool(rng.rand() < 0.7))
+
+    for k in range(n):
+        size = float(rng.uniform(0.3, 1.1))
+        r = rng.rand()
+        if r < 0.6:
+            o = place(prim(), size).set_material(material())
+        elif r < 0.8:
+            a = prim()
+            b = prim().set_transform(translate(rng.uniform(-0.6, 0.6), rng.uniform(-0.4, 0.4), rng.uniform(-0.6, 0.6)) * scale(0.8, 0.8, 0.8))
+            a.set_material(material())
+            b.set_material(material())
+            o = place(Shape.csg(("union", "intersection", "difference")[rng.randint(3)], a, b), size)
+        else:
+            g = Shape.group()
+            for _ in range(int(rng.randint(2, 5))):
+                g.add_child(prim().set_transform(translate(rng.uniform(-1.2, 1.2), rng.uniform(-0.5, 0.5), rng.uniform(-1.2, 1.2)) * scale(0.5, 0.5, 0.5)))
+            o = place(g, size).set_material(material())
+        if k == 3:
+            o.set_casts_shadow(False)
+        w.objects.append(o)
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0., 7., -14.), (0., 1., 6.), (0., 1., 0.))
+    return w, cam
+
+
+def instanced_small_meshes(seed=0, hsize=96, vsize=54, n=80, smooth=False):
+    """n separately parsed copies of one small OBJ mesh (a 4 x 4 height field: 32 triangles, optionally with vertex
+    normals) scattered with their own rotations and scales over a mirror floor, a few of them glass: a world of mesh
+    INSTANCES small enough for the brute-force oracle.  Every copy is an object of its own (one ITEM_MESH)."""
+    rng = np.random.RandomState(5100 + seed)
+    hgt = rng.uniform(-0.3, 0.5, size=(5, 5))
+    lines = []
+    for j in range(5):
+        for i in range(5):
+            lines.append("v %r %r %r" % (i / 2. - 1., float(hgt[j, i]), j / 2. - 1.))
+    if smooth:
+        for j in range(5):
+            for i in range(5):
+                nv = np.array([float(hgt[j, max(i - 1, 0)] - hgt[j, min(i + 1, 4)]), 1., float(hgt[max(j - 1, 0), i] - hgt[min(j + 1, 4), i])])
+                nv /= np.linalg.norm(nv)
+                lines.append("vn %r %r %r" % tuple(float(x) for x in nv))
+    vid = lambda i, j: j * 5 + i + 1
+    for j in range(4):
+        for i in range(4):
+            for tri in ((vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)), (vid(i, j), vid(i + 1, j + 1), vid(i, j + 1))):
+                lines.append("f " + " ".join(("%d//%d" % (v, v)) if smooth else str(v) for v in tri))
+    text = "\n".join(lines) + "\n"
+    w = World()
+    w.lights.append(Light.point_light((-10., 14., -12.), rt.WHITE))
+    w.objects.append(Shape.plane().set_material(Material(color=(0.4, 0.4, 0.45), specular=0.2, reflective=0.5)))
+    for k in range(n):
+        g, _ = rt.obj_to_group(text)
+        size = float(rng.uniform(0.5, 1.3))
+        g.set_transform(translate(rng.uniform(-12., 12.), rng.uniform(0.4, 3.), rng.uniform(-3., 22.)) * rotate(rng.uniform(0., 2. * PI), Axis.Y) *
+                        rotate(rng.uniform(-0.8, 0.8), Axis.Z) * scale(size, size, size))
+        if k % 7 == 3:
+            g.set_material(Material(color=(1., 1., 1.), diffuse=0.2, reflective=0.4, transparency=0.7, refractive_index=1.3))
+        else:
+            g.set_material(Material(color=tuple(rng.uniform(0.2, 1., 3)), diffuse=0.7, specular=0.4, reflective=0.25 if k % 3 == 0 else 0.))
+        w.objects.append(g)
+    cam = Camera(hsize, vsize, PI / 3.)
+    cam.transform = view_transform((0., 8., -15.), (0., 1., 8.), (0., 1., 0.))
+    return w, cam
+
+
 def cover_like_scene(hsize=200, vsize=200):
     """A many-cube/sphere scene in the spirit of render_cover_image (src/main.rs:876): exercises cubes with
     reflective and transparent materials plus a non-shadow-casting plane backdrop."""

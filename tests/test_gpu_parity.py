@@ -518,6 +518,59 @@ def test_world_space_cull_ranges_change_nothing(monkeypatch):
     assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
 
 
+def test_top_level_tree_changes_nothing(monkeypatch):
+    """Worlds of 64 or more bounded top-level objects get a BVH4 over the objects' world boxes (rt_program.cpp: emit_tlas;
+    rt_kernels.hip.h: tlas_next + the dispatcher in traverse) instead of nested cull ranges walked in program order.
+    Pure acceleration — the closest hit, intersections[0], every list and every shadow answer are functions of the SET of
+    intersections, not of the order objects are visited in (src/world.rs:46-55 sorts) — so frames with the tree, with
+    ranges only (RT_AMD_TLAS=0) and the oracle's brute force must agree: bit for bit between the two device paths at
+    sizes the oracle cannot reach, against the oracle at small ones, through every entry point."""
+    for builder, size, depth in ((lambda w, h: scenes.instanced_grid(w, h, grid=6), (960, 540), 6),      # 72 bounded objects, 36 mesh instances
+                                 (lambda w, h: scenes.many_objects_scene(1, w, h, n=140), (640, 360), 5),
+                                 (lambda w, h: scenes.many_objects_scene(2, w, h, n=30), (320, 180), 5)):   # under the threshold: ranges either way
+        monkeypatch.setenv("RT_AMD_TLAS", "0")
+        w0, cam0 = builder(*size)
+        ranges = cam0.render(w0, depth)
+        monkeypatch.delenv("RT_AMD_TLAS")
+        w1, cam1 = builder(*size)
+        tree = cam1.render(w1, depth)
+        shift = int(tree.hit_id[tree.hit_id > 0].min()) - int(ranges.hit_id[ranges.hit_id > 0].min())  # ids: process-wide counter
+        assert np.array_equal(np.where(tree.hit_id > 0, tree.hit_id - shift, 0), ranges.hit_id)
+        assert np.array_equal(tree.rgb, ranges.rgb, equal_nan=True) and np.array_equal(tree.flags, ranges.flags)
+        assert tree.stats.total_rays == ranges.stats.total_rays
+        for _ in range(2):   # and the graph-replayed frame (no rt_stats)
+            again = cam1.render(w1, depth, want_stats=False)
+            assert np.array_equal(again.rgb, tree.rgb, equal_nan=True) and np.array_equal(again.hit_id, tree.hit_id)
+    for seed in range(3):
+        w, cam = scenes.many_objects_scene(seed, 80, 45, n=90 + 30 * seed)
+        assert_image_parity(w, cam, 4)
+        o, d = _random_rays(1500, 20 + seed, center=(0., 1.5, 7.), radius=15.)
+        o[:50] *= 1e5      # from beyond the scene's reach: the boxes are not trusted, every object is visited
+        gc, gt, gi = w.intersect_world_batch(o, d, 64)
+        oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+        assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+        assert np.array_equal(w.is_shadowed_batch(o[50:]), ob.is_shadowed_batch(w, o[50:]))
+        g_rgb, g_id, g_fl = w.color_at_batch(o[50:400], d[50:400], 3)
+        o_rgb, o_id, o_fl = ob.color_at_batch(w, o[50:400], d[50:400], 3)
+        assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl)
+        err = np.abs(g_rgb - o_rgb)
+        err[np.isnan(g_rgb) & np.isnan(o_rgb)] = 0.
+        assert float(err.max()) < COLOR_TOL
+    for env in (None, "2"):    # mesh instances walked per lane / every object left to the wavefront: the oracle's frame either way
+        if env:
+            monkeypatch.setenv("RT_AMD_TLAS", env)
+        for smooth in (False, True):
+            w, cam = scenes.instanced_small_meshes(3 + int(smooth), 96, 54, n=80, smooth=smooth)
+            assert_image_parity(w, cam, 6)
+            o, d = _random_rays(3000, 77, center=(0., 1.5, 9.), radius=22.)
+            gc, gt, gi = w.intersect_world_batch(o, d, 64)
+            oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+            assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+            assert np.array_equal(w.is_shadowed_batch(o[:1000]), ob.is_shadowed_batch(w, o[:1000]))
+        if env:
+            monkeypatch.delenv("RT_AMD_TLAS")
+
+
 def _glass_mesh_world(instanced):
     """Transparent things in front of, behind and inside triangle meshes: the n1/n2 walk's lists hold many mesh
     triangles.  `instanced`: the same parsed mesh under two groups (its triangles then share equality classes, and the
@@ -1079,7 +1132,7 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
         w, cam = build(*size)
         ref = cam.render(w, depth=depth)
         for kw in ({"cull_ranges": 0}, {"passive_triangles": 0}, {"frame_graph": 0}, {"device_bvh": 1}, {"gather": 1},
-                   {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0},
+                   {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0}, {"top_level_tree": 0},
                    {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0, "share_meshes": 0,
                     "fuse_output": 0, "fuse_spawn": 0}):
             ms = rt.MultiScene(w, [0], **kw)

@@ -21,7 +21,7 @@ from rt_amd import Camera, view_transform
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as _f:
     KAT = json.load(_f)
 PI = math.pi
-CASES = [(hs.default_world, hs.build_default_world), (hs.composite_world, hs.build_composite_world)]
+CASES = [(hs.default_world, hs.build_default_world), (hs.composite_world, hs.build_composite_world), (hs.mesh_world, hs.build_mesh_world)]
 
 
 def oracle_render(desc_ptr, cam, depth=5):
@@ -40,13 +40,16 @@ def camera_for(which):
         k = KAT["camera_render_default_world"]
         cam = Camera(k["hsize"], k["vsize"], k["fov"])
         cam.transform = view_transform(k["from"], k["to"], k["up"])
-    else:
+    elif which == 1:
         cam = Camera(72, 48, PI / 3)
         cam.transform = view_transform((0.5, 2.5, -7.), (-0.5, 0.3, 0.), (0., 1., 0.))
+    else:
+        cam = Camera(80, 60, PI / 3)
+        cam.transform = view_transform((1.5, 2.5, -7.), (0.5, 0.3, 1.), (0., 1., 0.))
     return cam
 
 
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [0, 1, 2])
 def test_flattener_output_has_the_hand_written_content(which):
     hand, build = CASES[which]
     h = hand()
@@ -77,7 +80,7 @@ def test_oracle_on_hand_written_default_world_reproduces_reference_kats():
     assert cnt[0] == 4 and list(t[0, :4]) == KAT["world_intersect"]["t"] and list(oid[0, :4]) == [11, 12, 12, 11]   # world.rs:186-203
 
 
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [0, 1, 2])
 def test_oracle_renders_the_same_image_from_either_set_of_tables(which):
     hand, build = CASES[which]
     h = hand()
@@ -91,10 +94,12 @@ def test_oracle_renders_the_same_image_from_either_set_of_tables(which):
         (b[3].rays_primary, b[3].rays_reflect, b[3].rays_refract, b[3].rays_shadow)
     if which == 1:
         assert a[3].rays_reflect > 0 and a[3].rays_refract > 0 and len(np.unique(a[1])) >= 6
+    if which == 2:   # the mesh is seen (flat and smooth faces), refracts and reflects
+        assert a[3].rays_reflect > 0 and a[3].rays_refract > 0 and {207, 211} & set(np.unique(a[1]).tolist())
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [0, 1, 2])
 def test_device_from_hand_written_tables_matches_the_oracle(which):
     hand, build = CASES[which]
     h = hand()
@@ -116,7 +121,9 @@ def test_device_from_hand_written_tables_matches_the_oracle(which):
         rt.lib.rt_scene_destroy(scene)
     o_rgb, o_ids, o_flags, o_st = oracle_render(h.pointer(), cam)
     assert np.array_equal(ids, o_ids) and np.array_equal(flags, o_flags)
-    assert float(np.abs(rgb - o_rgb).max()) < 1e-9
+    err = np.abs(rgb - o_rgb)
+    err[np.isnan(rgb) & np.isnan(o_rgb)] = 0.
+    assert float(err.max()) < 1e-9
     assert (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow) == \
         (o_st.rays_primary, o_st.rays_reflect, o_st.rays_refract, o_st.rays_shadow)
     # and the same pixels as the device gets from the flattener's tables for the same scene
