@@ -1036,7 +1036,6 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);
     if (rc != RT_OK) { rt_set_error("%s", err.c_str()); return rc; }
-    if (prog.max_chain > MAX_CHAIN) { rt_set_error("transform chain deeper than %d levels", MAX_CHAIN); return RT_ERR_UNSUPPORTED; }
     int ndev = rt_device_count();
     if (ndev <= 0) { rt_set_error("no HIP device: this library has no CPU path"); return RT_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { rt_set_error("device %d out of range (have %d)", device, ndev); return RT_ERR_NO_DEVICE; }

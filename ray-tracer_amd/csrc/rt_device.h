@@ -32,7 +32,8 @@ constexpr int CSG_DEPTH_BIG = 64;  // ... in the overflow (BIG) kernel variants,
 #endif
 constexpr int LIST_CAP = RT_LIST_CAP;      // per-ray list for the n1/n2 container walk and rt_intersect_world
 constexpr int CONTAINER_CAP = LIST_CAP; // `containers` vector of prepare_computations: never longer than the list
-constexpr int MAX_CHAIN = 16;     // transform levels above a leaf
+// (transform chains have no depth limit: Shape::world_to_object / normal_to_world recurse without bound, src/shape.rs:394-420,
+// and so do the kernels — every chain is a [length, xform, ...] run of chain_pool walked to its end)
 
 // What prepare_computations needs to know about the hit node, in one 16-byte fetch (the SoA columns below stay for
 // the kernels that need a single field).

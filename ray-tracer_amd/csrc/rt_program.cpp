@@ -858,9 +858,18 @@ int validate(const rt_scene_desc& d, std::string& err) {
         if (d.ancestor_xform[a] < 0 || d.ancestor_xform[a] >= d.n_xforms) FAIL(RT_ERR_BAD_ARG, "ancestor %d: xform out of range", a);
         int32_t up = d.ancestor_parent[a];
         if (up < -1 || up >= d.n_ancestors) FAIL(RT_ERR_BAD_ARG, "ancestor %d: parent out of range", a);
-        int steps = 0;
-        for (int32_t c = a; c >= 0; c = d.ancestor_parent[c])
-            if (++steps > 64) FAIL(RT_ERR_UNSUPPORTED, "ancestor %d: parent chain deeper than 64 (or cyclic)", a);
+    }
+    {   // no cycles (every entry range-checked above); chains may be as deep as the scene graph is (src/shape.rs:394-420 recurses
+        // without bound): a group divide()d into a tall tree gets there.  state: 0 unseen, 1 on the current walk, 2 known to end
+        std::vector<unsigned char> state(size_t(d.n_ancestors), 0);
+        std::vector<int32_t> walk;
+        for (int32_t a = 0; a < d.n_ancestors; ++a) {
+            walk.clear();
+            int32_t c = a;
+            while (c >= 0 && state[size_t(c)] == 0) { state[size_t(c)] = 1; walk.push_back(c); c = d.ancestor_parent[c]; }
+            if (c >= 0 && state[size_t(c)] == 1) FAIL(RT_ERR_BAD_ARG, "ancestor %d: parent chain is cyclic", a);
+            for (int32_t v : walk) state[size_t(v)] = 2;
+        }
     }
     for (int32_t m = 0; m < d.n_materials; ++m)
         if (d.material_pattern[m] < -1 || d.material_pattern[m] >= d.n_patterns) FAIL(RT_ERR_BAD_ARG, "material %d: pattern out of range", m);

@@ -104,6 +104,31 @@ def test_random_meshes(first):
     assert not failures, failures
 
 
+@pytest.mark.parametrize("first", range(0, N_SEEDS, BATCH))
+def test_random_worlds_of_many_objects(first):
+    """Worlds large enough for the top-level tree (64+ bounded objects): random primitives / CSG / groups between unbounded
+    shapes, and scattered instances of one small mesh (flat or smooth) — the per-ray tree walk, the wavefront-uniform
+    object rounds and the per-lane mesh instances against the oracle; every other seed also with each object left to the
+    wavefront (RT_AMD_TLAS=2) and with ranges only (RT_AMD_TLAS=0)."""
+    failures = {}
+    for seed in range(first, min(first + BATCH, N_SEEDS)):
+        mode = seed % 4
+        env = {1: "2", 3: "0"}.get(mode)
+        if env:
+            os.environ["RT_AMD_TLAS"] = env
+        try:
+            if seed % 2:
+                builder = lambda s, w, h: scenes.instanced_small_meshes(s, w, h, n=70 + (s * 7) % 60, smooth=bool((s // 2) % 2))
+            else:
+                builder = lambda s, w, h: scenes.many_objects_scene(s, w, h, n=80 + (s * 11) % 90)
+            problems = compare(seed, depth=3 if seed % 3 else 5, builder=builder)
+        finally:
+            os.environ.pop("RT_AMD_TLAS", None)
+        if problems:
+            failures[seed] = problems
+    assert not failures, failures
+
+
 def _random_rays(rng, n):
     o = rng.normal(size=(n, 3))
     o = o / np.linalg.norm(o, axis=1)[:, None] * 13. * rng.uniform(0.02, 1.0, size=(n, 1)) + np.array([0., 1., 0.])

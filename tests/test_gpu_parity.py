@@ -313,6 +313,57 @@ def test_unbounded_cylinder_never_equal_to_itself():  # F14 end to end
 
 
 # ------------------------------------------------------------------ edge cases of the boundary
+def test_transform_chains_of_any_depth():
+    """Shape::world_to_object / normal_to_world recurse through the parent chain without bound (src/shape.rs:394-420) and
+    Shape::intersect applies one inverse per level (src/shape.rs:74-90): a glass sphere and a cube 40 groups deep (every
+    level with a transform of its own: the ray is transformed 41 times, the normal walks 41 levels back up), a triangle
+    mesh 20 groups deep, and a group of 200 spheres divide()d into a tall tree (src/group.rs:134-149) — against the oracle.
+    Round 2 refused chains deeper than 16 levels."""
+    def nest(shape, levels, k0=0):
+        for k in range(levels):
+            g = Shape.group().set_transform(translate(0.03 * ((k + k0) % 3 - 1), 0.02 * ((k + k0) % 2), 0.01) * rotate(0.05 * ((k % 5) - 2), Axis.Y) *
+                                            scale(1.01, 0.995, 1.0))
+            g.add_child(shape)
+            shape = g
+        return shape
+    w = World()
+    w.lights.append(Light.point_light((-6., 8., -9.), rt.WHITE))
+    w.objects.append(Shape.plane().set_transform(translate(0., -1.5, 0.)).set_material(Material(reflective=0.3)))
+    deep = Shape.group()
+    deep.add_child(Shape.glass_sphere().set_transform(translate(-1.2, 0., 0.)))
+    deep.add_child(Shape.cube().set_transform(translate(1.3, 0., 0.5) * scale(0.6, 0.6, 0.6)))
+    top = nest(deep, 40)
+    top.set_material(Material(color=(0.9, 0.95, 1.), diffuse=0.3, reflective=0.3, transparency=0.6, refractive_index=1.4))
+    w.objects.append(top)
+    mesh, _ = rt.obj_to_group(scenes.smooth_teapot_obj() if False else scenes.read_asset("teapot-low.obj"))
+    mesh.set_transform(translate(0., 1.2, 3.) * rotate(-PI / 2, Axis.X) * scale(0.08, 0.08, 0.08))
+    mtop = nest(mesh, 20, 1)
+    mtop.set_material(Material(color=(0.8, 0.5, 0.3), reflective=0.2))
+    w.objects.append(mtop)
+    many = Shape.group()
+    rng = np.random.RandomState(99)
+    for _ in range(200):
+        many.add_child(Shape.sphere().set_transform(translate(*rng.uniform(-4., 4., 3)) * scale(0.25, 0.25, 0.25)))
+    many.divide(1)
+    many.set_transform(translate(0., 3.5, 6.))
+    w.objects.append(many)
+    d = w.flatten().contents
+    depth = 0
+    for n in range(d.n_nodes):       # the deepest registry chain in the tables
+        a, k = d.node_ancestor[n], 0
+        while a >= 0:
+            a, k = d.ancestor_parent[a], k + 1
+        depth = max(depth, k)
+    assert depth >= 41
+    cam = Camera(96, 64, PI / 3)
+    cam.transform = view_transform((0.5, 2.5, -8.), (0., 1., 1.), (0., 1., 0.))
+    assert_image_parity(w, cam, 5)
+    o, dd = _random_rays(600, 5, center=(0., 1., 2.), radius=9.)
+    gc, gt, gi = w.intersect_world_batch(o, dd, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, dd, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+
+
 def test_empty_world_and_tiny_cameras():
     w = World()
     cam = Camera(16, 16, 1.0)
