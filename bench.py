@@ -392,7 +392,7 @@ def main():
         if args.scene == "teapot" and (args.width, args.height, args.depth) == (1920, 1080, 5):
             pmc_name = "pmc_traffic.json"
         elif args.scene == "grid" and (args.grid, args.width, args.height, args.depth) == (13, 7680, 4320, 8):
-            pmc_name = "r02_pmc_traffic_c5_grid13.json"
+            pmc_name = "r03_pmc_traffic_c5_grid13.json"
         pmc_path = os.path.join(ROOT, "profiles", pmc_name or "none")
         if os.path.exists(pmc_path):
             try:
