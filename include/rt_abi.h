@@ -11,10 +11,14 @@
  *
  * Conventions
  *   - All floating point is IEEE f64, ids and indices are int32 (reference: src/lib.rs:46,64-66).
- *   - Matrices are 4x4 row-major, 16 doubles.  Every inverse handed over must be affine:
- *     last row exactly (0,0,0,1) (sign of the zeros is ignored).  That is what
- *     Matrix::inverse (src/matrix.rs:124-154) yields for every transform built from
- *     src/transformation.rs.  rt_scene_create returns RT_ERR_UNSUPPORTED otherwise.
+ *   - Matrices are 4x4 row-major, 16 doubles.  The kernels the library is built around drop the
+ *     w of every tuple, which is exact while every inverse is affine — last row exactly
+ *     (0,0,0,1), what Matrix::inverse (src/matrix.rs:124-154) yields for every transform built
+ *     from src/transformation.rs.  A note on w: a scene with any other inverse (Matrix::new with
+ *     hand-made values), and any frame whose camera has no inverse (the reference then traces
+ *     Ray(ORIGIN, ORIGIN), src/camera.rs:44-46) or a non-affine one, is rendered by a second,
+ *     4-component path: the reference's algorithm with nothing taken away and no acceleration
+ *     structure, on the GPU, orders of magnitude slower.  Same entry points, same outputs.
  *   - Points/vectors are 3 doubles; the implied w is 1 for points and 0 for vectors.
  *   - The caller owns every input array for the duration of the call; the library copies
  *     what it keeps.  The caller allocates every output.  No ownership crosses the boundary
@@ -39,7 +43,7 @@ extern "C" {
 /* error classes */
 #define RT_OK 0
 #define RT_ERR_BAD_ARG (-1)      /* null pointer, negative count, index out of range          */
-#define RT_ERR_UNSUPPORTED (-2)  /* non-affine transform, non-invertible camera, ...          */
+#define RT_ERR_UNSUPPORTED (-2)  /* a size beyond a documented limit, an entry point a scene cannot serve */
 #define RT_ERR_HIP (-3)          /* a HIP runtime call failed (text has hipGetErrorString)    */
 #define RT_ERR_NO_DEVICE (-4)    /* no gfx950 device / device index out of range              */
 #define RT_ERR_OVERFLOW (-5)     /* rt_intersect_world / rt_is_shadowed: a ray needs more list entries than even the HBM
@@ -183,7 +187,7 @@ typedef struct rt_scene_desc {
 typedef struct rt_camera_desc {
     int32_t hsize;
     int32_t vsize;
-    int32_t invertible; /* transform.inverse().is_some(); 0 -> RT_ERR_UNSUPPORTED (src/camera.rs:44-46) */
+    int32_t invertible; /* transform.inverse().is_some(); 0: every pixel's ray is Ray(ORIGIN, ORIGIN), src/camera.rs:44-46 */
     int32_t _pad;
     double inverse[16]; /* transform.inverse() */
     double half_width;
@@ -283,6 +287,10 @@ typedef struct rt_scene_opts {
                                    nested cull ranges walked in program order; lanes whose rays meet different instances of
                                    a mesh walk them side by side: -1/1 yes, 0 ranges only, 2 the tree without per-lane mesh
                                    instances (every object left to the wavefront)                          [RT_AMD_TLAS]      */
+    /* (struct_size >= 48) */
+    int32_t four_components;    /* -1/0: the library's rule — the 4-component path (see the note on w below) only for scenes
+                                   and cameras that need it; 1: every call on this scene takes it, whatever its matrices
+                                   (orders of magnitude slower: for checking that path against the other) [RT_AMD_GENERAL]    */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is

@@ -23,6 +23,7 @@
 
 #include "rt_internal.h"
 #include "rt_kernels.hip.h"
+#include "rt_general.hip.h"
 
 using namespace rt;
 
@@ -140,6 +141,14 @@ struct rt_scene {
     int n_cus = 1;
     std::map<const void*, int> trav_grid;  // kernel -> workgroups that are resident at once on the whole device
     struct MultiState* multi = nullptr;    // rt_scene_create_multi: replicas on other devices, worker threads, RCCL
+    // The 4-component path (rt_general.hip.h): `general` = some inverse of the scene is not affine, every call takes that
+    // path; otherwise only frames whose camera has no inverse, or a non-affine one, do.  Its slab and counters are made
+    // on first use.
+    bool general = false;
+    GScene gs{};
+    GrowBuf g_slab, g_one;
+    int g_lanes = 0;
+    unsigned long long* g_h_counters = nullptr;  // pinned mirror of gs.counters
 };
 
 namespace {
@@ -640,17 +649,22 @@ int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, 
     return n_fix > 0 ? fix_overflowed_rays(s, st, n0, n_fix, D, stats) : RT_OK;
 }
 
-int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams& c, long long& n_slots, long long& n_valid) {
+// `general_cam`: callers that can take the 4-component path (or only need the tile geometry) pass a pointer and learn
+// whether the camera needs it — no inverse (src/camera.rs:44-46) or a non-affine one; with a null pointer such a camera
+// is an error.
+int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams& c, long long& n_slots, long long& n_valid,
+                  bool* general_cam = nullptr) {
     if (!cam) { rt_set_error("null camera"); return RT_ERR_BAD_ARG; }
     if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive (the reference underflows at 0, src/camera.rs:65-66)"); return RT_ERR_BAD_ARG; }
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) { rt_set_error("bad shard %d of %d", rank, n_ranks); return RT_ERR_BAD_ARG; }
-    if (!cam->invertible) {
+    const bool affine = cam->inverse[12] == 0. && cam->inverse[13] == 0. && cam->inverse[14] == 0. && cam->inverse[15] == 1.;
+    if (general_cam) *general_cam = !cam->invertible || !affine;
+    else if (!cam->invertible) {
         rt_set_error("camera transform is not invertible: the reference then traces Ray(ORIGIN, ORIGIN) for every pixel "
-                     "(src/camera.rs:44-46), a point used as a direction, which the w-free device tuples do not represent");
+                     "(src/camera.rs:44-46), a point used as a direction, which three components cannot carry");
         return RT_ERR_UNSUPPORTED;
-    }
-    if (!(cam->inverse[12] == 0. && cam->inverse[13] == 0. && cam->inverse[14] == 0. && cam->inverse[15] == 1.)) {
-        rt_set_error("camera inverse is not affine");
+    } else if (!affine) {
+        rt_set_error("camera inverse is not affine: its rays have origins with w != 1, which three components cannot carry");
         return RT_ERR_UNSUPPORTED;
     }
     std::memcpy(c.inv, cam->inverse, sizeof c.inv);
@@ -679,17 +693,90 @@ int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams
     return RT_OK;
 }
 
+// ---- the 4-component path (rt_general.hip.h)
+// Slab sizes: lists of 4096 intersections, 96 nested groups / CSG nodes, ray trees 62 deep: 150 KiB per lane, 2048 lanes hold 315 MB
+// (allocated the first time a scene takes this path).
+constexpr int G_LIST_CAP = 4096, G_DEPTH_CAP = 96, G_FRAME_CAP = 64, G_WGS = 32;
+int ensure_general(rt_scene* s) {
+    if (s->gs.slab) return RT_OK;
+    int rc;
+    const int lanes = G_WGS * GBLOCK;
+    const long long lane_bytes = (g_lane_bytes(G_LIST_CAP, G_DEPTH_CAP, G_FRAME_CAP) + 255) / 256 * 256;
+    if ((rc = grow(s->g_slab, size_t(lane_bytes) * size_t(lanes))) != RT_OK || (rc = grow(s->g_one, 8 * sizeof(double))) != RT_OK) return rc;
+    void* ctr = nullptr;
+    HIP_TRY(hipMalloc(&ctr, G_COUNT * sizeof(unsigned long long)));
+    s->allocs.push_back(ctr);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->g_h_counters), G_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
+    s->gs.counters = static_cast<unsigned long long*>(ctr);
+    s->gs.lane_bytes = lane_bytes;
+    s->gs.list_cap = G_LIST_CAP;
+    s->gs.depth_cap = G_DEPTH_CAP;
+    s->gs.frame_cap = G_FRAME_CAP;
+    s->gs.slab = static_cast<char*>(s->g_slab.p);
+    s->g_lanes = lanes;
+    return RT_OK;
+}
+int general_grid(rt_scene* s, long long n) { return int(std::max<long long>(1, std::min<long long>(G_WGS, (n + GBLOCK - 1) / GBLOCK))); }
+int general_counters_begin(rt_scene* s, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(s->gs.counters, 0, G_COUNT * sizeof(unsigned long long), st));
+    return RT_OK;
+}
+// after the stream has been waited for
+int general_counters_end(rt_scene* s, hipStream_t st, rt_stats* stats, long long times) {
+    HIP_TRY(hipMemcpyAsync(s->g_h_counters, s->gs.counters, G_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        stats->rays_reflect = (long long)s->g_h_counters[G_REFLECT] * times;
+        stats->rays_refract = (long long)s->g_h_counters[G_REFRACT] * times;
+        stats->rays_shadow = (long long)s->g_h_counters[G_SHADOW] * times;
+        stats->shaded_nodes = (long long)s->g_h_counters[G_SHADED] * times;
+    }
+    return RT_OK;
+}
+GCamera general_camera(const rt_camera_desc* cam) {
+    GCamera g;
+    std::memcpy(g.inv, cam->inverse, sizeof g.inv);
+    g.half_width = cam->half_width;
+    g.half_height = cam->half_height;
+    g.pixel_size = cam->pixel_size;
+    g.invertible = cam->invertible ? 1 : 0;
+    return g;
+}
+// Camera::render for one shard on the 4-component path; same outputs and stats as render_shard_impl below.
+int general_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb, int32_t* d_id,
+                   uint8_t* d_flags, rt_stats* stats, const CameraParams& c, long long n_slots, long long n_valid, bool frame) {
+    int rc;
+    if (opts->max_depth + 2 > G_FRAME_CAP) { rt_set_error("the 4-component path holds ray trees up to %d deep", G_FRAME_CAP - 2); return RT_ERR_UNSUPPORTED; }
+    if ((rc = ensure_general(s)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
+    const int depth = opts->max_depth < 0 ? 0 : opts->max_depth;
+    const GCamera g = general_camera(cam);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!g.invertible) {  // every pixel's ray is Ray(ORIGIN, ORIGIN): traced once
+        double* one = static_cast<double*>(s->g_one.p);
+        hipLaunchKernelGGL(k_general_one, dim3(1), dim3(GBLOCK), 0, st, s->ds, s->gs, g, depth, one);
+        hipLaunchKernelGGL(k_general_fill, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, static_cast<const double*>(one), d_rgb, d_id, d_flags, frame ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(k_general_render, dim3(general_grid(s, n_slots)), dim3(GBLOCK), 0, st, s->ds, s->gs, g, c, n_slots, depth, d_rgb, d_id, d_flags, frame ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    if ((rc = general_counters_end(s, st, stats, g.invertible ? 1 : n_valid)) != RT_OK) return rc;
+    if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
 // Camera::render for one shard, all work ordered on `st`, complete (the host has waited) when it returns.
 int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb,
                       int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots, bool frame = false) {
     long long n_valid = 0;
-    int rc = camera_params(cam, opts->rank, opts->n_ranks, c, n_slots, n_valid);
+    bool general_cam = false;
+    int rc = camera_params(cam, opts->rank, opts->n_ranks, c, n_slots, n_valid, &general_cam);
     if (rc != RT_OK) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->rays_primary = n_valid;
     }
     if (n_slots == 0) return RT_OK;
+    if (s->general || general_cam) return general_render(s, cam, opts, st, d_rgb, d_id, d_flags, stats, c, n_slots, n_valid, frame);
     const int D = opts->max_depth < 0 || !s->spawns ? 0 : opts->max_depth;  // see run_levels
     if ((rc = ensure_level(s, 0, n_slots)) != RT_OK || (rc = ensure_counters(s, D + 2)) != RT_OK) return rc;
     auto raygen = [&]() { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots); };
@@ -980,7 +1067,7 @@ namespace {
 // rt_scene_opts with every -1 resolved: the field, else its RT_AMD_* variable, else the default
 struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
-    bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true;
+    bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true, general = false;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
 };
 void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
@@ -1001,6 +1088,7 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     k.fuse_output = pick(v.fuse_output, "RT_AMD_FUSE_OUTPUT", true);
     k.fuse_spawn = pick(v.fuse_spawn, "RT_AMD_FUSE_SPAWN", true);
     k.tlas = pick(v.top_level_tree, "RT_AMD_TLAS", true);
+    k.general = pick(v.four_components, "RT_AMD_GENERAL", false);
     {   // 2: the tree, but every object left to the wavefront (no per-lane mesh instances)
         const char* e = std::getenv("RT_AMD_TLAS");
         k.tlas_instances = !(v.top_level_tree == 2 || (v.top_level_tree < 0 && e && std::atoi(e) == 2));
@@ -1113,6 +1201,16 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
             for (int k = 0; k < 3; ++k) { li[size_t(i) * 6 + k] = d.light_position[3 * size_t(i) + k]; li[size_t(i) * 6 + 3 + k] = d.light_intensity[3 * size_t(i) + k]; }
         UP(upload(s, li, &s->ds.light));
     }
+    // what the 4-component path reads (rt_general.hip.h): the descriptor's tree tables and full inverses as they came in
+    UP(upload(s, vec_of(d.xform_inverse, size_t(d.n_xforms) * 16), &s->gs.xf16));
+    UP(upload(s, vec_of(d.pattern_inverse, size_t(d.n_patterns) * 16), &s->gs.pat16));
+    UP(upload(s, vec_of(d.node_xform, size_t(d.n_nodes)), &s->gs.node_xform));
+    UP(upload(s, vec_of(d.node_subtree_end, size_t(d.n_nodes)), &s->gs.node_end));
+    UP(upload(s, vec_of(d.node_ancestor, size_t(d.n_nodes)), &s->gs.node_ancestor));
+    UP(upload(s, vec_of(d.ancestor_parent, size_t(d.n_ancestors)), &s->gs.anc_parent));
+    UP(upload(s, vec_of(d.ancestor_xform, size_t(d.n_ancestors)), &s->gs.anc_xform));
+    UP(upload(s, vec_of(d.csg_op, size_t(d.n_csg)), &s->gs.csg_op));
+    s->general = prog.general || knobs.general;
     UP(upload(s, prog.items, &s->ds.items));
     UP(upload(s, prog.chain_pool, &s->ds.chain_pool));
     UP(upload(s, prog.bvh, &s->ds.bvh));
@@ -1252,6 +1350,9 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->fix_d_counters) (void)hipFree(s->fix_d_counters);
     if (s->fix_h_counters) (void)hipHostFree(s->fix_h_counters);
     if (s->arena.p) (void)hipFree(s->arena.p);
+    if (s->g_slab.p) (void)hipFree(s->g_slab.p);
+    if (s->g_one.p) (void)hipFree(s->g_one.p);
+    if (s->g_h_counters) (void)hipHostFree(s->g_h_counters);
     if (s->ovf_index.p) (void)hipFree(s->ovf_index.p);
     for (GrowBuf* b : {&s->out_rgb, &s->out_id, &s->out_flags, &s->frame_rgb, &s->frame_id, &s->frame_flags, &s->in_a, &s->in_b,
                        &s->misc_a, &s->misc_b, &s->misc_c})
@@ -1336,7 +1437,8 @@ int rt_assemble_strided(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks,
     for (int r = 0; r < n_ranks; ++r) {
         CameraParams c;
         long long n_slots = 0, n_valid = 0;
-        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid);
+        bool any_cam = false;
+        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid, &any_cam);
         if (rc != RT_OK) return rc;
         if (shard_stride > 0 && n_slots > shard_stride) { rt_set_error("shard %d holds %lld pixels, the stride is %lld", r, n_slots, (long long)shard_stride); return RT_ERR_BAD_ARG; }
         if (n_slots)
@@ -1375,7 +1477,8 @@ int rt_assemble_quantised(rt_scene* s, const rt_camera_desc* cam, int32_t n_rank
     for (int r = 0; r < n_ranks; ++r) {
         CameraParams c;
         long long n_slots = 0, n_valid = 0;
-        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid);
+        bool any_cam = false;
+        int rc = camera_params(cam, r, n_ranks, c, n_slots, n_valid, &any_cam);
         if (rc != RT_OK) return rc;
         if (shard_stride > 0 && n_slots > shard_stride) { rt_set_error("shard %d holds %lld pixels, the stride is %lld", r, n_slots, (long long)shard_stride); return RT_ERR_BAD_ARG; }
         if (n_slots)
@@ -1631,7 +1734,8 @@ int rt_render_multi(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts
     for (int r = 0; r < N; ++r) {
         CameraParams c;
         long long n_slots = 0, n_valid = 0;
-        if ((rc = camera_params(cam, r, N, c, n_slots, n_valid)) != RT_OK) return rc;
+        bool any_cam = false;
+        if ((rc = camera_params(cam, r, N, c, n_slots, n_valid, &any_cam)) != RT_OK) return rc;
         if (n_slots == 0) continue;
         const size_t off = gathered ? size_t(r) * size_t(n_max) : 0;
         const double* rgb_in = want_rgb ? (gathered ? static_cast<const double*>(ms->g_rgb.p) : static_cast<const double*>(s->out_rgb.p)) + off * 3 : nullptr;
@@ -1741,6 +1845,20 @@ int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double
     if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, rb)) != RT_OK || (rc = grow(s->out_rgb, rb)) != RT_OK ||
         (rc = grow(s->out_id, size_t(n_rays) * sizeof(int32_t))) != RT_OK || (rc = grow(s->out_flags, size_t(n_rays))) != RT_OK)
         return rc;
+    if (s->general) {  // some inverse of the scene is not affine: the 4-component path (rt_general.hip.h)
+        if (remaining + 2 > G_FRAME_CAP) { rt_set_error("the 4-component path holds ray trees up to %d deep", G_FRAME_CAP - 2); return RT_ERR_UNSUPPORTED; }
+        if ((rc = ensure_general(s)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_general_color_at, dim3(general_grid(s, n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays,
+                           static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), int(remaining < 0 ? 0 : remaining),
+                           static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p), static_cast<uint8_t*>(s->out_flags.p));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(rgb_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
+        if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, s->out_id.p, size_t(n_rays) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, s->out_flags.p, size_t(n_rays), hipMemcpyDeviceToHost, st));
+        return general_counters_end(s, st, stats, 1);
+    }
     if ((rc = ensure_level(s, 0, n_rays)) != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
@@ -1780,7 +1898,10 @@ static int list_pass(rt_scene* s, bool big, int64_t n, const double* origins, co
     int32_t* ids = static_cast<int32_t*>(s->misc_c.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
-    if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    if (s->general) {
+        if ((rc = ensure_general(s)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_list, dim3(general_grid(s, n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+    } else if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     else rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     s->big = false;
@@ -1806,11 +1927,11 @@ int rt_intersect_world(rt_scene* s, int64_t n_rays, const double* origins, const
     int rc = list_pass(s, false, n_rays, origins, directions, max_hits, count_out, t_out, object_id_out, flags.data());
     if (rc != RT_OK) return rc;
     // rays whose list (or a CSG subtree's pending list) did not fit the per-lane arrays: again, with the lists in HBM
-    int cap = LIST_CAP;
+    int cap = s->general ? G_LIST_CAP : LIST_CAP;  // (the 4-component path has one list size and no second round)
     std::vector<int64_t> todo;
     for (int64_t i = 0; i < n_rays; ++i)
         if (count_out[i] > cap || (flags[size_t(i)] & RT_FLAG_LIST_OVERFLOW)) todo.push_back(i);
-    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty(); ++round) {
+    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty() && !s->general; ++round) {
         if ((rc = ensure_arena(s, round)) != RT_OK) return rc;
         cap = ARENA_ROUNDS[round].list_cap;
         const size_t m = todo.size();
@@ -1849,7 +1970,10 @@ static int shadow_pass(rt_scene* s, bool big, int64_t n, const double* points, u
     uint8_t* o = static_cast<uint8_t*>(s->misc_a.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
-    if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
+    if (s->general) {
+        if ((rc = ensure_general(s)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_shadow, dim3(general_grid(s, n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, p, o, fl);
+    } else if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     else rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     s->big = false;
@@ -1872,7 +1996,7 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
     for (int64_t i = 0; i < n_points; ++i)
         if (flags[size_t(i)] & RT_FLAG_LIST_OVERFLOW) todo.push_back(i);
     const size_t nl = size_t(s->n_lights);
-    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty(); ++round) {
+    for (int round = 0; round < N_ARENA_ROUNDS && !todo.empty() && !s->general; ++round) {
         if ((rc = ensure_arena(s, round)) != RT_OK) return rc;
         const size_t m = todo.size();
         std::vector<double> p(m * 3);
@@ -1898,6 +2022,7 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
 int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t* hit_id_out,
                             double* comps_out, uint8_t* flags_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n_rays < 0 || !origins || !directions || !hit_id_out || !comps_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     if (n_rays == 0) return RT_OK;
     hipStream_t st = s->stream;
@@ -1934,6 +2059,7 @@ static int leaf_node_arg(rt_scene* s, int32_t node) {
 
 int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, const double* uv, double* normals_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n < 0 || !points || !normals_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     int rc = leaf_node_arg(s, node);
     if (rc != RT_OK) return rc;
@@ -1954,6 +2080,7 @@ int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, con
 int rt_lighting(rt_scene* s, int32_t node, int32_t light, int64_t n, const double* points, const double* eyes, const double* normals,
                 const uint8_t* in_shadow, double* rgb_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n < 0 || !points || !eyes || !normals || !in_shadow || !rgb_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     int rc = leaf_node_arg(s, node);
     if (rc != RT_OK) return rc;

@@ -1371,9 +1371,14 @@ __device__ __forceinline__ int as_i32(double x) {  // Rust `as i32`: saturating,
 }
 
 // Pattern::pattern_at_shape (src/pattern.rs:23-35) and the six pattern_at bodies
+__device__ __forceinline__ V3 pattern_at(const DScene& S, int pat, V3 p);
 __device__ __forceinline__ V3 pattern_at_shape(const DScene& S, int pat, int node, V3 world_point) {
     V3 object_point = world_to_object(S, node, world_point);
     V3 p = xf_point(S.pat_inv + (size_t)pat * 12, object_point);
+    return pattern_at(S, pat, p);
+}
+// the pattern_at bodies (src/pattern.rs:72-177): x, y, z of the pattern-space point only
+__device__ __forceinline__ V3 pattern_at(const DScene& S, int pat, V3 p) {
     const double* __restrict__ ab = S.pat_ab + (size_t)pat * 6;
     V3 a = mk(ab[0], ab[1], ab[2]), b = mk(ab[3], ab[4], ab[5]);
     switch (S.pat_kind[pat]) {
@@ -1566,8 +1571,8 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
     n2_out = n2;
 }
 
-__device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, double n1, double n2) {  // src/intersection.rs:97-115
-    double cosv = dot(eye_vector, normal_vector);
+// Intersection::schlick (src/intersection.rs:97-115) from cos = eye_vector . normal_vector
+__device__ __forceinline__ double schlick_from(double cosv, double n1, double n2) {
     if (n1 > n2) {
         double n = n1 / n2;
         double sin2_t = (n * n) * (1. - cosv * cosv);
@@ -1579,6 +1584,9 @@ __device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, doubl
     double r0 = q * q;
     double x = 1. - cosv;
     return r0 + (1. - r0) * (x * ((x * x) * (x * x)));
+}
+__device__ __forceinline__ double schlick(V3 eye_vector, V3 normal_vector, double n1, double n2) {
+    return schlick_from(dot(eye_vector, normal_vector), n1, n2);
 }
 
 // ---------------------------------------------------------------------------------------------------------

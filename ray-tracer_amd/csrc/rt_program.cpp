@@ -827,7 +827,8 @@ bool affine_row(const double* m16) {
         return code;                                     \
     } while (0)
 
-int validate(const rt_scene_desc& d, std::string& err) {
+int validate(const rt_scene_desc& d, std::string& err, bool& general) {
+    general = false;
     if (d.abi_version != RT_ABI_VERSION) FAIL(RT_ERR_BAD_ARG, "abi_version %d, library speaks %d", d.abi_version, RT_ABI_VERSION);
     if (d.n_nodes < 0 || d.n_xforms < 1 || d.n_ancestors < 0 || d.n_groups < 0 || d.n_csg < 0 || d.n_conics < 0 ||
         d.n_triangles < 0 || d.n_smooth < 0 || d.n_materials < 0 || d.n_patterns < 0 || d.n_lights < 0)
@@ -847,11 +848,13 @@ int validate(const rt_scene_desc& d, std::string& err) {
         FAIL(RT_ERR_BAD_ARG, "null table with a non-zero count");
     for (int i = 0; i < 16; ++i)
         if (d.xform_inverse[i] != ((i % 5 == 0) ? 1. : 0.)) FAIL(RT_ERR_BAD_ARG, "xform 0 must be the exact identity");
+    // An inverse whose last row is not 0,0,0,1 (only Matrix::new with hand-made values gets there: every product of
+    // src/transformation.rs is affine, and so is its cofactor inverse) sends points out of Matrix * Tuple with w != 1: such
+    // a scene runs on the 4-component path
     for (int32_t x = 0; x < d.n_xforms; ++x)
-        if (!affine_row(d.xform_inverse + size_t(x) * 16))
-            FAIL(RT_ERR_UNSUPPORTED, "xform %d: inverse is not affine (last row must be 0,0,0,1)", x);
+        if (!affine_row(d.xform_inverse + size_t(x) * 16)) general = true;
     for (int32_t q = 0; q < d.n_patterns; ++q) {
-        if (!affine_row(d.pattern_inverse + size_t(q) * 16)) FAIL(RT_ERR_UNSUPPORTED, "pattern %d: inverse is not affine", q);
+        if (!affine_row(d.pattern_inverse + size_t(q) * 16)) general = true;
         if (d.pattern_kind[q] < RT_PAT_STRIPED || d.pattern_kind[q] > RT_PAT_TEST) FAIL(RT_ERR_BAD_ARG, "pattern %d: bad kind", q);
     }
     for (int32_t a = 0; a < d.n_ancestors; ++a) {
@@ -912,8 +915,13 @@ int validate(const rt_scene_desc& d, std::string& err) {
 
 int compile_program(const rt_scene_desc& d, Program& out, std::string& err, const ProgramOpts& opts) {
     const double t_begin = Compiler::now();
-    int rc = validate(d, err);
+    int rc = validate(d, err, out.general);
     if (rc != RT_OK) return rc;
+    if (out.general) {  // nothing to compile: the 4-component path walks the descriptor's own tables
+        out.chain_pool.assign(1, 0);
+        out.node_nchain.assign(size_t(d.n_nodes), 0);
+        return RT_OK;
+    }
     const double t_validated = Compiler::now();
     Compiler c(d, out);
     c.opts = opts;

@@ -82,6 +82,8 @@ struct Program {
     int32_t meshes_shared = 0;         // ITEM_MESH items that took the tree of an earlier, identical mesh
     std::vector<double> mesh_box;      // 6 per ITEM_MESH: padded f64 bounds of the whole mesh
     bool has_csg = false;
+    bool general = false;              // some inverse is not affine: no program is compiled, the scene runs on the 4-component
+                                       // path (rt_general.hip.h) and everything above stays empty
     int32_t meshes_built_on_gpu = 0;   // meshes whose tree topology came from rt_lbvh.hip
     // Worlds of many bounded top-level objects (>= TLAS_MIN_OBJECTS): instead of nested ITEM_CULL ranges walked in program
     // order, every bounded object is a range of its own — [ITEM_CULL with the object's world box, the object's items) —

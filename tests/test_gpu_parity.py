@@ -378,15 +378,6 @@ def test_empty_world_and_tiny_cameras():
     assert w.color_at_batch(np.zeros((0, 3)), np.zeros((0, 3)))[0].shape == (0, 3)
 
 
-def test_non_invertible_camera_is_an_error():
-    w = World.default()
-    cam = Camera(8, 8, 1.0)
-    cam.transform = scale(0., 1., 1.)
-    with pytest.raises(rt.RtError) as e:
-        cam.render(w)
-    assert e.value.code == rt.RT_ERR_UNSUPPORTED
-
-
 def test_world_without_lights_is_black_but_traced():
     w = World.default()
     w.lights.clear()
