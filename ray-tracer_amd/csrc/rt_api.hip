@@ -2022,7 +2022,6 @@ int rt_is_shadowed(rt_scene* s, int64_t n_points, const double* points, uint8_t*
 int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, const double* directions, int32_t* hit_id_out,
                             double* comps_out, uint8_t* flags_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
-    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n_rays < 0 || !origins || !directions || !hit_id_out || !comps_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     if (n_rays == 0) return RT_OK;
     hipStream_t st = s->stream;
@@ -2038,7 +2037,10 @@ int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, 
     int32_t* ids = static_cast<int32_t*>(s->misc_a.p);
     double* comps = static_cast<double*>(s->misc_b.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
-    if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
+    if (s->general) {  // the 4-component path; x, y, z of every tuple are handed back
+        if ((rc = ensure_general(s)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_comps, dim3(general_grid(s, n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays, o, d, ids, comps, fl);
+    } else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     else rc = launch_trav(s, st, k_comps<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipGetLastError());
@@ -2059,7 +2061,6 @@ static int leaf_node_arg(rt_scene* s, int32_t node) {
 
 int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, const double* uv, double* normals_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
-    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n < 0 || !points || !normals_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     int rc = leaf_node_arg(s, node);
     if (rc != RT_OK) return rc;
@@ -2069,8 +2070,12 @@ int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, con
     if ((rc = grow(s->in_a, rb)) != RT_OK || (rc = grow(s->in_b, size_t(n) * 2 * sizeof(double))) != RT_OK || (rc = grow(s->out_rgb, rb)) != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(s->in_a.p, points, rb, hipMemcpyHostToDevice, st));
     if (uv) HIP_TRY(hipMemcpyAsync(s->in_b.p, uv, size_t(n) * 2 * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_normal_at, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (long long)n, static_cast<const double*>(s->in_a.p),
-                       uv ? static_cast<const double*>(s->in_b.p) : nullptr, static_cast<double*>(s->out_rgb.p));
+    if (s->general)
+        hipLaunchKernelGGL(k_general_normal_at, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, s->gs, (int)node, (long long)n,
+                           static_cast<const double*>(s->in_a.p), uv ? static_cast<const double*>(s->in_b.p) : nullptr, static_cast<double*>(s->out_rgb.p));
+    else
+        hipLaunchKernelGGL(k_normal_at, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (long long)n, static_cast<const double*>(s->in_a.p),
+                           uv ? static_cast<const double*>(s->in_b.p) : nullptr, static_cast<double*>(s->out_rgb.p));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(normals_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2080,7 +2085,6 @@ int rt_normal_at(rt_scene* s, int32_t node, int64_t n, const double* points, con
 int rt_lighting(rt_scene* s, int32_t node, int32_t light, int64_t n, const double* points, const double* eyes, const double* normals,
                 const uint8_t* in_shadow, double* rgb_out) {
     if (!check_scene(s)) return RT_ERR_BAD_ARG;
-    if (s->general) { rt_set_error("not available for scenes with a non-affine inverse (they render through rt_render / rt_color_at / rt_intersect_world / rt_is_shadowed only)"); return RT_ERR_UNSUPPORTED; }
     if (n < 0 || !points || !eyes || !normals || !in_shadow || !rgb_out) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     int rc = leaf_node_arg(s, node);
     if (rc != RT_OK) return rc;
@@ -2095,9 +2099,14 @@ int rt_lighting(rt_scene* s, int32_t node, int32_t light, int64_t n, const doubl
     HIP_TRY(hipMemcpyAsync(s->in_b.p, eyes, rb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->misc_b.p, normals, rb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->misc_a.p, in_shadow, size_t(n), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lighting, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (int)light, (long long)n,
-                       static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), static_cast<const double*>(s->misc_b.p),
-                       static_cast<const uint8_t*>(s->misc_a.p), static_cast<double*>(s->out_rgb.p));
+    if (s->general)
+        hipLaunchKernelGGL(k_general_lighting, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, s->gs, (int)node, (int)light, (long long)n,
+                           static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), static_cast<const double*>(s->misc_b.p),
+                           static_cast<const uint8_t*>(s->misc_a.p), static_cast<double*>(s->out_rgb.p));
+    else
+        hipLaunchKernelGGL(k_lighting, dim3(blocks_for(n)), dim3(BLOCK), 0, st, s->ds, (int)node, (int)light, (long long)n,
+                           static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), static_cast<const double*>(s->misc_b.p),
+                           static_cast<const uint8_t*>(s->misc_a.p), static_cast<double*>(s->out_rgb.p));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rgb_out, s->out_rgb.p, rb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -268,8 +268,8 @@ __device__ __forceinline__ V4 g_normal_step(const GScene& G, int xform, V4 n) { 
     nn.w = 0.;
     return normalize4(nn);
 }
-// Shape::normal_at (src/shape.rs:92-108); `first` / `hit` index the list (F5: a smooth triangle reads intersections[0])
-__device__ inline V4 g_normal_at(const DScene& S, const GScene& G, const GLane& M, int node, V4 world_point, int first, int hit, unsigned& flags) {
+// Shape::normal_at (src/shape.rs:92-108); hu, hv: the u, v SmoothTriangle::normal_at is handed
+__device__ inline V4 g_normal_at_uv(const DScene& S, const GScene& G, int node, V4 world_point, double hu, double hv) {
     const V4 p = g_world_to_object(G, node, world_point);
     const int kind = S.node_kind[node], prm = S.node_param[node];
     V4 n;
@@ -277,21 +277,13 @@ __device__ inline V4 g_normal_at(const DScene& S, const GScene& G, const GLane& 
         n = sub4(p, mk4(0., 0., 0., 1.));  // src/sphere.rs:65-67
     } else {
         V3 tri_n = mk(0., 0., 0.);
-        double cmin = 0., cmax = 0., hu = 0., hv = 0.;
+        double cmin = 0., cmax = 0.;
         if (kind == RT_TRIANGLE) {
             const double* __restrict__ t = S.tri + (size_t)prm * 12;
             tri_n = mk(t[9], t[10], t[11]);
         } else if (kind == RT_CYLINDER || kind == RT_CONE) {
             cmin = S.conic[2 * prm];
             cmax = S.conic[2 * prm + 1];
-        } else if (kind == RT_SMOOTH_TRIANGLE) {
-            int src = first;
-            if (S.node_kind[M.lk[first] >> 2] != RT_SMOOTH_TRIANGLE) {  // `hit.u.unwrap()` panics in the reference
-                flags |= RT_FLAG_REF_PANIC_UV;
-                src = hit;
-            }
-            hu = M.lu[src];
-            hv = M.lv[src];
         }
         n = vec4(local_normal_at(S, kind, prm, xyz(p), hu, hv, tri_n, cmin, cmax));
     }
@@ -302,6 +294,53 @@ __device__ inline V4 g_normal_at(const DScene& S, const GScene& G, const GLane& 
 
 __device__ __forceinline__ bool g_shape_eq(const DScene& S, int a, int b) {
     return S.node_eq_class[a] >= 0 && S.node_eq_class[a] == S.node_eq_class[b];
+}
+
+// Intersection::prepare_computations (src/intersection.rs:38-95) for entry `h` of the lane's sorted list of n
+struct GComps {
+    V4 point, eye, normal, over, under, reflect;
+    double t, n1, n2, u, v;
+    int32_t node;
+    bool inside;
+};
+__device__ inline void g_prepare(const DScene& S, const GScene& G, const GLane& M, V4 ro, V4 rd, int n, int h, unsigned& flags, GComps& c) {
+    const double t = M.lt[h];
+    const int node = M.lk[h] >> 2;
+    c.t = t;
+    c.node = node;
+    c.point = add4(ro, mul4(rd, t));  // Ray::position, src/ray.rs:21-23
+    c.u = M.lu[h];
+    c.v = M.lv[h];
+    if (S.node_kind[node] == RT_SMOOTH_TRIANGLE) {  // F5: the u, v of intersections[0] (:40)
+        if (S.node_kind[M.lk[0] >> 2] == RT_SMOOTH_TRIANGLE) { c.u = M.lu[0]; c.v = M.lv[0]; }
+        else flags |= RT_FLAG_REF_PANIC_UV;  // `hit.u.unwrap()` panics in the reference; the hit's own u, v stand in
+    }
+    c.normal = g_normal_at_uv(S, G, node, c.point, c.u, c.v);
+    c.eye = neg4(rd);
+    c.inside = dot4(c.normal, c.eye) < 0.;
+    if (c.inside) c.normal = neg4(c.normal);
+    c.over = add4(c.point, mul4(c.normal, EPS));
+    c.under = sub4(c.point, mul4(c.normal, EPS));
+    c.reflect = reflect4(rd, c.normal);
+    double n1 = 0., n2 = 0.;
+    int nc = 0;
+    for (int i = 0; i < n; ++i) {  // every intersection, no break, the last match wins (:57-80; F6)
+        const int xn = M.lk[i] >> 2;
+        const bool is_self = near_eq(M.lt[i], t) && g_shape_eq(S, xn, node);  // Intersection::eq, :15-19
+        if (is_self) n1 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[M.cont[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        int found = -1;
+        for (int k = 0; k < nc && found < 0; ++k)
+            if (g_shape_eq(S, M.cont[k], xn)) found = k;
+        if (found >= 0) {
+            for (int k = found; k + 1 < nc; ++k) M.cont[k] = M.cont[k + 1];
+            --nc;
+        } else {
+            M.cont[nc++] = xn;
+        }
+        if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[M.cont[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+    }
+    c.n1 = n1;
+    c.n2 = n2;
 }
 
 // Material::lighting (src/material.rs:97-129) with Pattern::pattern_at_shape (src/pattern.rs:23-35)
@@ -379,36 +418,12 @@ __device__ inline void g_color_at(const DScene& S, const GScene& G, const GLane&
                 continue;
             }
             ++tally.shaded;
-            // ---- Intersection::prepare_computations (src/intersection.rs:38-95)
-            const double t = M.lt[h];
-            const int node = M.lk[h] >> 2;
+            GComps c;
+            g_prepare(S, G, M, f.o, f.d, n, h, flags, c);
+            const int node = c.node;
             if (fp == 0) hit_id = S.node_object_id[node];
-            const V4 point = add4(f.o, mul4(f.d, t));  // Ray::position, src/ray.rs:21-23
-            V4 normal_vector = g_normal_at(S, G, M, node, point, 0, h, flags);
-            const V4 eye_vector = neg4(f.d);
-            if (dot4(normal_vector, eye_vector) < 0.) normal_vector = neg4(normal_vector);
-            const V4 over_point = add4(point, mul4(normal_vector, EPS));
-            const V4 under_point = sub4(point, mul4(normal_vector, EPS));
-            const V4 reflect_vector = reflect4(f.d, normal_vector);
-            double n1 = 0., n2 = 0.;
-            {   // every intersection, no break, the last match wins (:57-80; F6)
-                int nc = 0;
-                for (int i = 0; i < n; ++i) {
-                    const int xn = M.lk[i] >> 2;
-                    const bool is_self = near_eq(M.lt[i], t) && g_shape_eq(S, xn, node);  // Intersection::eq, :15-19
-                    if (is_self) n1 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[M.cont[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-                    int found = -1;
-                    for (int k = 0; k < nc && found < 0; ++k)
-                        if (g_shape_eq(S, M.cont[k], xn)) found = k;
-                    if (found >= 0) {
-                        for (int k = found; k + 1 < nc; ++k) M.cont[k] = M.cont[k + 1];
-                        --nc;
-                    } else {
-                        M.cont[nc++] = xn;
-                    }
-                    if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[M.cont[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-                }
-            }
+            const V4 normal_vector = c.normal, eye_vector = c.eye, over_point = c.over, under_point = c.under, reflect_vector = c.reflect;
+            const double n1 = c.n1, n2 = c.n2;
             // ---- World::shade_hit (src/world.rs:57-79): the lights (the list is free again from here on)
             const double* __restrict__ m = S.mat + (size_t)S.node_material[node] * RT_MAT_STRIDE;
             V3 surface = mk(0., 0., 0.);
@@ -610,6 +625,59 @@ __global__ __launch_bounds__(GBLOCK) void k_general_shadow(DScene S, GScene G, l
         for (int l = 0; l < S.n_lights; ++l) out[i * S.n_lights + l] = g_is_shadowed(S, G, M, p, l, flags, n_shadow) ? 1 : 0;
         flags_out[i] = (uint8_t)flags;
     }
+}
+
+// rt_prepare_computations: every field of Computations for the hit of each ray (x, y, z of the tuples; columns RT_COMP_*)
+__global__ __launch_bounds__(GBLOCK) void k_general_comps(DScene S, GScene G, long long n, const double* __restrict__ origins,
+                                                          const double* __restrict__ dirs, int32_t* hit_id_out, double* out, uint8_t* flags_out) {
+    const long long lane = (long long)blockIdx.x * GBLOCK + threadIdx.x, lanes = (long long)gridDim.x * GBLOCK;
+    const GLane M = g_lane(G, lane);
+    for (long long i = lane; i < n; i += lanes) {
+        unsigned flags = 0;
+        const V4 o = mk4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 1.), d = mk4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.);
+        const int m = g_intersect_world(S, G, M, o, d, flags);
+        const int h = g_hit_index(M, m);
+        double* r = out + i * RT_COMP_COUNT;
+        for (int k = 0; k < RT_COMP_COUNT; ++k) r[k] = 0.;
+        hit_id_out[i] = 0;
+        if (h >= 0) {
+            GComps c;
+            g_prepare(S, G, M, o, d, m, h, flags, c);
+            hit_id_out[i] = S.node_object_id[c.node];
+            auto put = [&](int at, V4 v) { r[at] = v.x; r[at + 1] = v.y; r[at + 2] = v.z; };
+            r[RT_COMP_T] = c.t;
+            put(RT_COMP_POINT, c.point); put(RT_COMP_EYE, c.eye); put(RT_COMP_NORMAL, c.normal);
+            r[RT_COMP_INSIDE] = c.inside ? 1. : 0.;
+            put(RT_COMP_OVER, c.over); put(RT_COMP_UNDER, c.under); put(RT_COMP_REFLECT, c.reflect);
+            r[RT_COMP_N1] = c.n1;
+            r[RT_COMP_N2] = c.n2;
+            r[RT_COMP_SCHLICK] = schlick_from(dot4(c.eye, c.normal), c.n1, c.n2);
+            r[RT_COMP_U] = c.u;
+            r[RT_COMP_V] = c.v;
+        }
+        flags_out[i] = (uint8_t)flags;
+    }
+}
+
+// rt_normal_at: Shape::normal_at of one leaf for a batch of world points (w = 1)
+__global__ __launch_bounds__(BLOCK) void k_general_normal_at(DScene S, GScene G, int node, long long n, const double* __restrict__ points,
+                                                             const double* __restrict__ uv, double* out) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V4 nv = g_normal_at_uv(S, G, node, mk4(points[3 * i], points[3 * i + 1], points[3 * i + 2], 1.), uv ? uv[2 * i] : 0., uv ? uv[2 * i + 1] : 0.);
+    out[3 * i] = nv.x; out[3 * i + 1] = nv.y; out[3 * i + 2] = nv.z;
+}
+
+// rt_lighting: Material::lighting with one leaf's material for a batch of (point, eye vector, normal vector, in_shadow)
+__global__ __launch_bounds__(BLOCK) void k_general_lighting(DScene S, GScene G, int node, int light, long long n, const double* __restrict__ points,
+                                                            const double* __restrict__ eyes, const double* __restrict__ normals,
+                                                            const uint8_t* __restrict__ in_shadow, double* out) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3 c = g_lighting(S, G, node, light, mk4(points[3 * i], points[3 * i + 1], points[3 * i + 2], 1.),
+                            mk4(eyes[3 * i], eyes[3 * i + 1], eyes[3 * i + 2], 0.), mk4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.),
+                            in_shadow[i] != 0);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
 }
 
 }  // namespace rt

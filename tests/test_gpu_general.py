@@ -175,10 +175,6 @@ def test_scene_with_projective_transforms(seed):
     assert_image_parity(w, cam, 3)
     cam.transform = scale(1., 0., 1.)                # and one without an inverse
     assert_image_parity(w, cam, 4)
-    # the unit-test entry points speak three components: not for such a scene
-    with pytest.raises(rt.RtError) as e:
-        w.prepare_computations_batch([(0., 1., -5.)], [(0., 0., 1.)])
-    assert e.value.code == rt.RT_ERR_UNSUPPORTED
 
 
 # ------------------------------------------------------------------ ordinary scenes through the 4-component path
@@ -212,3 +208,16 @@ def test_random_worlds_on_the_four_component_path(first, monkeypatch):
         if problems:
             failures[seed] = problems
     assert not failures, failures
+
+
+def test_reference_unit_test_tables_on_the_four_component_path(monkeypatch):
+    """Every table of tests/golden/reference_kats.json that tests/test_gpu_kats.py replays through the C ABI, replayed once
+    more with each scene forced onto the 4-component path: pins that path to the reference's own unit tests directly."""
+    import test_gpu_kats as kats
+    monkeypatch.setenv("RT_AMD_GENERAL", "1")
+    ran = 0
+    for name in sorted(dir(kats)):
+        if name.startswith("test_"):
+            getattr(kats, name)()
+            ran += 1
+    assert ran >= 20
