@@ -93,6 +93,50 @@ def cpu_baseline_all_cores(args):
             "cpu_s": round(sum(r[2] for r in res), 2)}
 
 
+def measure_traffic(args):
+    """HBM bytes per launch of every kernel of this workload, from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: one
+    counter per pass, as MI355X_MICROARCH.md prescribes) of a two-frame child run of this script; units and the gfx950
+    half-count correction of FETCH_SIZE as in scripts/pmc_traffic.py.  None when it cannot be done here (no rocprofv3,
+    this run is being profiled itself, a pass failed or ran into its time limit): the caller falls back to profiles/."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not os.path.exists(exe) or (profiled and args.traffic != "measure"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import pmc_traffic
+    except Exception:
+        return None
+    child = ["python3", os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--traffic", "file",
+             "--scene", args.scene, "--grid", str(args.grid), "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
+    tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "170", exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200)
+            if r.returncode != 0:
+                return None
+            per[counter] = pmc_traffic.per_kernel(out, counter)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k in set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"]):
+        fk, fn = per["FETCH_SIZE"].get(k, [0.0, 0])
+        wk, wn = per["WRITE_SIZE"].get(k, [0.0, 0])
+        if k.startswith("k_") and fn and wn:
+            res[k] = {"hbm_read_bytes_per_launch": int(fk * 1024.0 * 2.0 / fn), "hbm_write_bytes_per_launch": int(wk * 1024.0 / wn),
+                      "hbm_bytes_per_launch": int(fk * 1024.0 * 2.0 / fn + wk * 1024.0 / wn), "launches_sampled": fn}
+    return res or None
+
+
 def main():
     # stdout carries exactly ONE line, the JSON result: libraries that print there (RCCL's version banner at communicator
     # creation, for one) are sent to stderr by pointing file descriptor 1 at it for the rest of the run
@@ -116,6 +160,11 @@ def main():
                     help="sharded path: what travels over xGMI. f64: the f64 RGB shards (24 B/px); u8: scale_color on each rank's "
                          "shard first (rt_quantise), 3 B/px, the root assembles the u8 frame canvas_to_ppm reads")
     ap.add_argument("--cpu-stride", type=int, default=12)
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file"],
+                    help="roofline.traffic (HBM bytes per launch of the dominant kernel). measure: two rocprofv3 --pmc passes "
+                         "(FETCH_SIZE, WRITE_SIZE; each its own short child run of this script) before this process touches "
+                         "the GPU; file: the committed figure under profiles/; auto: measure at N = 1 when rocprofv3 is there "
+                         "and this run is not itself being profiled, else file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +175,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
 
+    measured_traffic = None
+    if world == 1 and not args.rehearse_sharded and args.traffic != "file":
+        measured_traffic = measure_traffic(args)   # child processes; before torch / HIP are initialised in this one
     cpu_all = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu_all = cpu_baseline_all_cores(args)   # before torch / HIP are initialised in this process
@@ -394,11 +446,22 @@ def main():
         elif args.scene == "grid" and (args.grid, args.width, args.height, args.depth) == (13, 7680, 4320, 8):
             pmc_name = "r03_pmc_traffic_c5_grid13.json"
         pmc_path = os.path.join(ROOT, "profiles", pmc_name or "none")
-        if os.path.exists(pmc_path):
+        traffic_source = None
+        if measured_traffic and dom in measured_traffic:
+            pmc = measured_traffic[dom]["hbm_bytes_per_launch"]
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each over a two-frame child "
+                              "run of this workload before the timed region (%d launches of %s sampled; read = FETCH_SIZE KiB x 1024 x 2, "
+                              "the gfx950 half-count correction, %d B; written = WRITE_SIZE KiB x 1024, %d B)"
+                              % (measured_traffic[dom]["launches_sampled"], dom, measured_traffic[dom]["hbm_read_bytes_per_launch"],
+                                 measured_traffic[dom]["hbm_write_bytes_per_launch"]))
+        elif os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pmc = None
+            if pmc is not None:
+                traffic_source = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; not collected "
+                                  "in this run)" % pmc_name)
         achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         roofline = {"kernel": dom, "bound": "fp64_valu", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": pmc,
@@ -409,8 +472,7 @@ def main():
                               "the same launch schedule as the timed frames (plain enqueue where the timed frames replay "
                               "it as one HIP graph), no host wait between launches" % n_ev,
                     "flops_source": "work counters of one instrumented frame (want_counters=1) x SURVEY 8(d) constants",
-                    "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                       "committed; not collected in this run)" % pmc_name) if pmc is not None else None,
+                    "traffic_source": traffic_source,
                     "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "

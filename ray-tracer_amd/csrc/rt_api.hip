@@ -1224,6 +1224,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     s->ds.n_items = int32_t(prog.items.size());
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
     s->ds.cull_reach = prog.cull_reach;
+    s->ds.cull_min_dir2 = prog.cull_min_dir2;
     s->ds.tlas_root = prog.tlas_root;
     s->ds.n_linear = prog.n_linear;
     s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));

@@ -503,26 +503,32 @@ __device__ __forceinline__ double slab_rcp(double d) {
 // (p - o) / d by at most 3 * 2^-24 |a| + 2^-24 |o / d|.  The test widens the [tmin, tmax] interval by
 // 2^-20 (|tmin| + |tmax|) + 2^-21 max_axis |o_f * inv_f| — four times that budget on each side.  A ray whose f32
 // origin, reciprocal or budget is not finite takes the f64 test instead.
+// Round 3: one instruction per plane instead of two.  With q = fl32(o_f * inv_f) kept per axis, a plane distance is
+// fma(p, inv_f, -q) — a single rounding of p * inv_f - q, so its error against the exact (p - o) / d is at most
+// 2^-24 (|a| + |p / d| + |o / d|) <= 2 * 2^-24 |a| + 2 * 2^-24 |o / d| (rounding of the result, of inv_f, of q): inside the
+// same budget (the widening below is 16 * 2^-24 |a| + 8 * 2^-24 |o / d|).  An explicit fmaf in a conservative f32
+// pre-test changes no reference arithmetic (-ffp-contract=off still keeps every f64 formula unfused).
 struct RayF {
-    float ox, oy, oz, ix, iy, iz, budget;
+    float qx, qy, qz, ix, iy, iz, budget;
     bool ok;
 };
 __device__ __forceinline__ RayF make_rayf(V3 o, V3 inv) {
     RayF r;
-    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     r.ix = (float)inv.x; r.iy = (float)inv.y; r.iz = (float)inv.z;
-    const float e = fmaxf(fmaxf(fabsf(r.ox * r.ix), fabsf(r.oy * r.iy)), fabsf(r.oz * r.iz));
+    r.qx = ox * r.ix; r.qy = oy * r.iy; r.qz = oz * r.iz;
+    const float e = fmaxf(fmaxf(fabsf(r.qx), fabsf(r.qy)), fabsf(r.qz));
     r.budget = e * 4.76837158203125e-07f;  // 2^-21
-    r.ok = fabsf(r.ox) < 3e38f && fabsf(r.oy) < 3e38f && fabsf(r.oz) < 3e38f && fabsf(r.ix) < 3e38f && fabsf(r.iy) < 3e38f &&
-           fabsf(r.iz) < 3e38f && r.budget < 3e38f;  // NaN fails every comparison
+    r.ok = fabsf(ox) < 3e38f && fabsf(oy) < 3e38f && fabsf(oz) < 3e38f && fabsf(r.ix) < 3e38f && fabsf(r.iy) < 3e38f &&
+           fabsf(r.iz) < 3e38f && r.budget < 3e38f;  // NaN fails every comparison (budget < 3e38 also says every q is finite)
     return r;
 }
 template <bool GAP = false>
 __device__ __forceinline__ bool bvh_box_f32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r, float tlo,
                                             float thi, float& tnear, float gap_lo = 0.f) {
-    const float ax = (lox - r.ox) * r.ix, bx = (hix - r.ox) * r.ix;
-    const float ay = (loy - r.oy) * r.iy, by = (hiy - r.oy) * r.iy;
-    const float az = (loz - r.oz) * r.iz, bz = (hiz - r.oz) * r.iz;
+    const float ax = __builtin_fmaf(lox, r.ix, -r.qx), bx = __builtin_fmaf(hix, r.ix, -r.qx);
+    const float ay = __builtin_fmaf(loy, r.iy, -r.qy), by = __builtin_fmaf(hiy, r.iy, -r.qy);
+    const float az = __builtin_fmaf(loz, r.iz, -r.qz), bz = __builtin_fmaf(hiz, r.iz, -r.qz);
     const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     float slack = 9.5367431640625e-07f * (fabsf(tmin) + fabsf(tmax)) + r.budget;  // 2^-20
@@ -849,7 +855,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     };
     // From very far away the reference's quadratics report tangent hits outside the padded bounds of the ITEM_CULL
     // ranges (rt_program.cpp: WBox::reach): a ray that starts beyond the scene's reach is never culled by them.
-    const bool cull_trusted = HAS_CULL && fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) < S.cull_reach;
+    // (the direction's length only matters to scenes with a bounded cube: rt_program.cpp, world_box)
+    const bool cull_trusted = HAS_CULL && fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) < S.cull_reach &&
+                              (S.cull_min_dir2 == 0. || dot(rd, rd) >= S.cull_min_dir2);
     const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
     const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
     const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);

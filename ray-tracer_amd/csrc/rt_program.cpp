@@ -516,12 +516,26 @@ struct Compiler {
         switch (kind) {
             case RT_SPHERE: return to_world(unit_lo, unit_hi, chain);
             case RT_CUBE: {
-                // never bounded: check_axis treats an object-space direction component below EPSILON as parallel
-                // (src/cube.rs:64-78), so that axis' slab is all of t when the ORIGIN lies between its planes, and the
-                // reference then reports hits whose points are |t| * EPSILON outside the cube — arbitrarily far for a
-                // distant origin.  Found by tests/test_gpu_fuzz.py (a cube scaled by 17 seen from 1e5 away).
-                WBox w;
-                w.bounded = false;
+                // check_axis treats an object-space direction component below EPSILON as parallel (src/cube.rs:64-78): that
+                // axis' slab is then all of t when the ORIGIN lies between its planes, so the ray may drift out of the slab
+                // by |d_k| |t| < EPSILON |t| (object units) before it meets the other axes' faces, and the reference reports
+                // that hit — outside the unit cube, arbitrarily far for a distant origin (found by tests/test_gpu_fuzz.py: a
+                // cube scaled by 17 seen from 1e5 away).  What the reference accepts at parameter t lies in the cube grown
+                // by EPSILON |t|, so a box grown by CUBE_PAD covers every hit with |t| <= CUBE_PAD / EPSILON; and a ray whose
+                // origin is within CUBE_REACH (L-infinity) of everything in the box, with a direction at least 1/2 long,
+                // meets the box only at |t| <= 2 sqrt(3) CUBE_REACH <= CUBE_PAD / EPSILON.  Other rays do not trust the ranges
+                // (cull_reach, cull_min_dir2).  Round 2 left cubes unbounded: C4's ranges then held three objects out of nine.
+                constexpr double CUBE_PAD = 0.05, CUBE_REACH = 1400.;
+                static_assert(2. * 1.7320508075688774 * CUBE_REACH <= CUBE_PAD / 0.00001, "cube padding does not cover its reach");
+                const double h = 1. + CUBE_PAD;
+                const double lo[3] = {-h, -h, -h}, hi[3] = {h, h, h};
+                WBox w = to_world(lo, hi, chain);
+                w.reach = std::min(w.reach, CUBE_REACH);
+                // a cube that large, or that far out, would take the whole program's reach (a minimum) down with it: it
+                // stays unbounded, as every cube was before
+                for (int k = 0; k < 3 && w.bounded; ++k)
+                    if (std::max(std::fabs(w.lo[k]), std::fabs(w.hi[k])) > CUBE_REACH / 2.) w.bounded = false;
+                if (w.bounded) p.cull_min_dir2 = 0.25;
                 return w;
             }
             case RT_PLANE: { WBox w; w.bounded = false; return w; }

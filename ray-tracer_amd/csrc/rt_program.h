@@ -95,6 +95,8 @@ struct Program {
     int32_t tlas_levels = 0;           // BVH4 levels of the top-level tree (its share of the traversal stack)
     bool has_cull = false;             // the program has ITEM_CULL ranges
     double cull_reach = 0.;            // ... trusted for rays whose origin has max |coordinate| below this (WBox::reach)
+    double cull_min_dir2 = 0.;         // ... and whose direction is at least this long, squared (0.25 once a cube is bounded: its
+                                       // padding covers the reference's leak only up to a parameter |t| of CUBE_PAD / EPSILON)
     bool has_smooth = false;
     bool all_cast_shadow = true;
     int32_t max_chain = 0;

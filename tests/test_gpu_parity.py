@@ -686,6 +686,73 @@ def test_cull_ranges_are_not_trusted_from_very_far_away():
     assert np.array_equal(g_id, o_id) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
 
 
+def test_cubes_under_cull_ranges_keep_the_hits_the_reference_leaks():
+    """Cube::check_axis calls an object-space direction component below EPSILON parallel (src/cube.rs:64-78): with the origin
+    between that axis' planes the slab is all of t, so a ray that drifts out of it on the way — by up to EPSILON |t| —
+    still gets its hits on the other axes' faces: points OUTSIDE the cube.  Round 3 puts cubes under the cull ranges with
+    a box grown by 5 % (rt_program.cpp: CUBE_PAD), trusted for origins within 1400 of it and directions at least 1/2 long.
+    Nearly face-parallel rays that start just inside a slab and leave it before they reach the cube — from 10 to 1e5
+    cube sizes away, unit directions and very short ones — must list what the oracle lists, in a world of eight bounded
+    objects (cubes of scale 0.5 to 17 among them) and in one where a CSG of cubes and a group of cubes are culled."""
+    rng = np.random.default_rng(11)
+    for variant in range(2):
+        w = World()
+        w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
+        cubes = []
+        for k in range(8):
+            s = (0.5, 1., 2., 17., 1.5, 0.8, 3., 1.)[k]
+            c = (9. * k - 30., 0.5 * k, 4. * (k % 3))
+            cube = Shape.cube().set_transform(translate(*c) * rotate(0.2 * k, Axis.Y) * scale(s, s, s))
+            cubes.append((c, s, 0.2 * k))
+            if variant == 1 and k % 4 == 1:
+                cube = Shape.csg("difference", cube, Shape.cube().set_transform(translate(c[0], c[1] + 0.5 * s, c[2]) * scale(s, s, s)))
+            elif variant == 1 and k % 4 == 2:
+                g = Shape.group()
+                g.add_child(cube)
+                cube = g
+            w.objects.append(cube)
+            w.objects.append(Shape.sphere().set_transform(translate(c[0], c[1] + 2.5 * s, c[2]) * scale(0.5, 0.5, 0.5)))
+        o, d = [], []
+        for c, s, angle in cubes:
+            ca, sa = math.cos(angle), math.sin(angle)
+            for dist in (10., 100., 1e3, 1e5):
+                for _ in range(40):
+                    # object space: travel along +z towards the cube, start just inside the x slab, drift out of it
+                    t_reach = dist * s
+                    drift = rng.uniform(0.2e-5, 0.99e-5)            # |d_x| < EPSILON in object space: "parallel"
+                    x0 = 1. - rng.uniform(0., 1.) * drift * t_reach / s * rng.uniform(0.2, 1.)
+                    po = np.array([x0, rng.uniform(-0.9, 0.9), -t_reach / s])
+                    do = np.array([drift, 0., 1. / s])             # object-space direction of a unit-length world ray
+                    # to world: p_w = T R S p_o (R about y)
+                    def fw(v, point):
+                        v = v * s
+                        v = np.array([ca * v[0] + sa * v[2], v[1], -sa * v[0] + ca * v[2]])
+                        return v + np.array(c) if point else v
+                    ow, dw = fw(po, True), fw(do, False)
+                    scale_dir = rng.choice([1., 1., 1e-3, 3.])
+                    o.append(ow); d.append(dw * scale_dir)
+        o, d = np.array(o), np.array(d)
+        gc, gt, gi = w.intersect_world_batch(o, d, 32)
+        oc, ot, oi = ob.intersect_world_batch(w, o, d, 32)
+        assert np.array_equal(gc, oc) and np.array_equal(gt, ot, equal_nan=True) and np.array_equal(gi, oi)
+        assert (oc > 0).sum() > 100
+        g_rgb, g_id, g_fl = w.color_at_batch(o, d, 3)
+        o_rgb, o_id, o_fl = ob.color_at_batch(w, o, d, 3)
+        assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl)
+        err = np.abs(g_rgb - o_rgb)
+        err[np.isnan(g_rgb) & np.isnan(o_rgb)] = 0.
+        err[np.isinf(g_rgb) & (g_rgb == o_rgb)] = 0.
+        # relative above 1: a direction three units long takes pow(reflect . eye, shininess) to 1e70
+        err = err / np.maximum(1., np.nan_to_num(np.abs(o_rgb), nan=1., posinf=1.))
+        assert float(err.max()) < COLOR_TOL
+        assert np.array_equal(w.is_shadowed_batch(o[::5]), ob.is_shadowed_batch(w, o[::5]))
+    # and the leak is real: some listed hit lies outside its cube by more than the generic 1e-7 padding would cover
+    w = World()
+    w.objects.append(Shape.cube())
+    t = ob.intersect_world_batch(w, np.array([[1. - 1e-4, 0., -500.]]), np.array([[0.9e-5, 0., 1.]]), 4)
+    assert t[0][0] == 2 and abs((1. - 1e-4) + 0.9e-5 * t[1][0, 0]) > 1. + 1e-3
+
+
 def test_gpu_built_bvh_changes_nothing(monkeypatch):
     """rt_scene_opts.device_bvh / RT_AMD_DEVICE_BVH=1: meshes of 1024+ distinct triangles are built entirely on the GPU
     (csrc/rt_lbvh.hip: Morton sort, binary radix tree, bottom-up boxes, leaves, BVH4 collapse).  A BVH only decides which
