@@ -619,11 +619,14 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
                     if (!hit) ch[c] = INT32_MIN;
                 }
             } else {
+                // (rays whose f32 image is not finite are rare: the f64 reciprocals are made again here instead of being kept
+                // in six registers through every step of every traversal)
+                const V3 inv64 = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     double t;
                     bool hit = bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c],
-                                       (double)hi[2][c], o, inv, tlo, thi, t) & (ch[c] != INT32_MIN);
+                                       (double)hi[2][c], o, inv64, tlo, thi, t) & (ch[c] != INT32_MIN);
                     tn[c] = hit ? (t == t ? (float)t : -INFINITY) : INFINITY;
                     if (!hit) ch[c] = INT32_MIN;
                 }
