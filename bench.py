@@ -118,8 +118,9 @@ def measure_traffic(args):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
-            cmd = ["timeout", "-s", "KILL", "170", exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200)
+            # a pass over two frames takes 10-20 s (8K: 30 s); a profiler that hangs is killed, and the committed figure is used
+            cmd = ["timeout", "-s", "KILL", "90", exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return None
             per[counter] = pmc_traffic.per_kernel(out, counter)
