@@ -694,29 +694,35 @@ int camera_params(const rt_camera_desc* cam, int rank, int n_ranks, CameraParams
 }
 
 // ---- the 4-component path (rt_general.hip.h)
-// Slab sizes: lists of 4096 intersections, 96 nested groups / CSG nodes, ray trees 62 deep: 150 KiB per lane, 2048 lanes hold 315 MB
-// (allocated the first time a scene takes this path).
-constexpr int G_LIST_CAP = 4096, G_DEPTH_CAP = 96, G_FRAME_CAP = 64, G_WGS = 32;
-int ensure_general(rt_scene* s) {
-    if (s->gs.slab) return RT_OK;
+// Slab sizes: lists of 4096 intersections, 96 nested groups / CSG nodes, ray trees 62 deep: 150 KiB per lane.  The slab
+// grows with the largest batch a scene has been asked for — one workgroup of 64 lanes per 64 rays, up to 256 workgroups
+// (16384 lanes, 2.5 GB) — and is made the first time a scene takes this path.
+constexpr int G_LIST_CAP = 4096, G_DEPTH_CAP = 96, G_FRAME_CAP = 64, G_WGS_MAX = 256;
+int general_grid(long long n) { return int(std::max<long long>(1, std::min<long long>(G_WGS_MAX, (n + GBLOCK - 1) / GBLOCK))); }
+int ensure_general(rt_scene* s, long long n) {
     int rc;
-    const int lanes = G_WGS * GBLOCK;
+    const int lanes = general_grid(n) * GBLOCK;
     const long long lane_bytes = (g_lane_bytes(G_LIST_CAP, G_DEPTH_CAP, G_FRAME_CAP) + 255) / 256 * 256;
-    if ((rc = grow(s->g_slab, size_t(lane_bytes) * size_t(lanes))) != RT_OK || (rc = grow(s->g_one, 8 * sizeof(double))) != RT_OK) return rc;
-    void* ctr = nullptr;
-    HIP_TRY(hipMalloc(&ctr, G_COUNT * sizeof(unsigned long long)));
-    s->allocs.push_back(ctr);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->g_h_counters), G_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
-    s->gs.counters = static_cast<unsigned long long*>(ctr);
-    s->gs.lane_bytes = lane_bytes;
-    s->gs.list_cap = G_LIST_CAP;
-    s->gs.depth_cap = G_DEPTH_CAP;
-    s->gs.frame_cap = G_FRAME_CAP;
-    s->gs.slab = static_cast<char*>(s->g_slab.p);
-    s->g_lanes = lanes;
+    if (!s->gs.counters) {
+        if ((rc = grow(s->g_one, 8 * sizeof(double))) != RT_OK) return rc;
+        void* ctr = nullptr;
+        HIP_TRY(hipMalloc(&ctr, G_COUNT * sizeof(unsigned long long)));
+        s->allocs.push_back(ctr);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->g_h_counters), G_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
+        s->gs.counters = static_cast<unsigned long long*>(ctr);
+        s->gs.lane_bytes = lane_bytes;
+        s->gs.list_cap = G_LIST_CAP;
+        s->gs.depth_cap = G_DEPTH_CAP;
+        s->gs.frame_cap = G_FRAME_CAP;
+    }
+    if (lanes > s->g_lanes) {
+        if (s->stream) HIP_TRY(hipStreamSynchronize(s->stream));  // nothing of an earlier call may still be using the old slab
+        if ((rc = grow(s->g_slab, size_t(lane_bytes) * size_t(lanes))) != RT_OK) { s->g_lanes = 0; s->gs.slab = nullptr; return rc; }
+        s->gs.slab = static_cast<char*>(s->g_slab.p);
+        s->g_lanes = lanes;
+    }
     return RT_OK;
 }
-int general_grid(rt_scene* s, long long n) { return int(std::max<long long>(1, std::min<long long>(G_WGS, (n + GBLOCK - 1) / GBLOCK))); }
 int general_counters_begin(rt_scene* s, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(s->gs.counters, 0, G_COUNT * sizeof(unsigned long long), st));
     return RT_OK;
@@ -747,7 +753,7 @@ int general_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts*
                    uint8_t* d_flags, rt_stats* stats, const CameraParams& c, long long n_slots, long long n_valid, bool frame) {
     int rc;
     if (opts->max_depth + 2 > G_FRAME_CAP) { rt_set_error("the 4-component path holds ray trees up to %d deep", G_FRAME_CAP - 2); return RT_ERR_UNSUPPORTED; }
-    if ((rc = ensure_general(s)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
+    if ((rc = ensure_general(s, cam->invertible ? n_slots : 1)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
     const int depth = opts->max_depth < 0 ? 0 : opts->max_depth;
     const GCamera g = general_camera(cam);
     const auto t0 = std::chrono::steady_clock::now();
@@ -756,7 +762,7 @@ int general_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts*
         hipLaunchKernelGGL(k_general_one, dim3(1), dim3(GBLOCK), 0, st, s->ds, s->gs, g, depth, one);
         hipLaunchKernelGGL(k_general_fill, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, n_slots, static_cast<const double*>(one), d_rgb, d_id, d_flags, frame ? 1 : 0);
     } else {
-        hipLaunchKernelGGL(k_general_render, dim3(general_grid(s, n_slots)), dim3(GBLOCK), 0, st, s->ds, s->gs, g, c, n_slots, depth, d_rgb, d_id, d_flags, frame ? 1 : 0);
+        hipLaunchKernelGGL(k_general_render, dim3(general_grid(n_slots)), dim3(GBLOCK), 0, st, s->ds, s->gs, g, c, n_slots, depth, d_rgb, d_id, d_flags, frame ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     if ((rc = general_counters_end(s, st, stats, g.invertible ? 1 : n_valid)) != RT_OK) return rc;
@@ -1848,10 +1854,10 @@ int rt_color_at(rt_scene* s, int64_t n_rays, const double* origins, const double
         return rc;
     if (s->general) {  // some inverse of the scene is not affine: the 4-component path (rt_general.hip.h)
         if (remaining + 2 > G_FRAME_CAP) { rt_set_error("the 4-component path holds ray trees up to %d deep", G_FRAME_CAP - 2); return RT_ERR_UNSUPPORTED; }
-        if ((rc = ensure_general(s)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
+        if ((rc = ensure_general(s, n_rays)) != RT_OK || (rc = general_counters_begin(s, st)) != RT_OK) return rc;
         HIP_TRY(hipMemcpyAsync(s->in_a.p, origins, rb, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(s->in_b.p, directions, rb, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_general_color_at, dim3(general_grid(s, n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays,
+        hipLaunchKernelGGL(k_general_color_at, dim3(general_grid(n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays,
                            static_cast<const double*>(s->in_a.p), static_cast<const double*>(s->in_b.p), int(remaining < 0 ? 0 : remaining),
                            static_cast<double*>(s->out_rgb.p), static_cast<int32_t*>(s->out_id.p), static_cast<uint8_t*>(s->out_flags.p));
         HIP_TRY(hipGetLastError());
@@ -1900,8 +1906,8 @@ static int list_pass(rt_scene* s, bool big, int64_t n, const double* origins, co
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
     if (s->general) {
-        if ((rc = ensure_general(s)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_general_list, dim3(general_grid(s, n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
+        if ((rc = ensure_general(s, n)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_list, dim3(general_grid(n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     } else if (big) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_list<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
     else rc = launch_trav(s, st, k_list<SC_CULL>, chunks_for(n), s->ds, (long long)n, o, d, (int)max_hits, cnt, tt, ids, fl);
@@ -1972,8 +1978,8 @@ static int shadow_pass(rt_scene* s, bool big, int64_t n, const double* points, u
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     s->big = big;
     if (s->general) {
-        if ((rc = ensure_general(s)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_general_shadow, dim3(general_grid(s, n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, p, o, fl);
+        if ((rc = ensure_general(s, n)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_shadow, dim3(general_grid(n)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n, p, o, fl);
     } else if (big) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS | SC_BIG>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_shadow_points<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n), s->ds, (long long)n, p, o, fl);
     else rc = launch_trav(s, st, k_shadow_points<SC_CULL>, chunks_for(n), s->ds, (long long)n, p, o, fl);
@@ -2039,8 +2045,8 @@ int rt_prepare_computations(rt_scene* s, int64_t n_rays, const double* origins, 
     double* comps = static_cast<double*>(s->misc_b.p);
     uint8_t* fl = static_cast<uint8_t*>(s->out_flags.p);
     if (s->general) {  // the 4-component path; x, y, z of every tuple are handed back
-        if ((rc = ensure_general(s)) != RT_OK) return rc;
-        hipLaunchKernelGGL(k_general_comps, dim3(general_grid(s, n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays, o, d, ids, comps, fl);
+        if ((rc = ensure_general(s, n_rays)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_general_comps, dim3(general_grid(n_rays)), dim3(GBLOCK), 0, st, s->ds, s->gs, (long long)n_rays, o, d, ids, comps, fl);
     } else if (s->has_csg || s->has_tlas) rc = launch_trav(s, st, k_comps<SC_CSG | SC_CULL | SC_TLAS>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     else rc = launch_trav(s, st, k_comps<SC_CULL>, chunks_for(n_rays), s->ds, (long long)n_rays, o, d, ids, comps, fl);
     if (rc != RT_OK) return rc;

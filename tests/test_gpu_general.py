@@ -171,6 +171,11 @@ def test_scene_with_projective_transforms(seed):
     g, _ = assert_image_parity(w, cam, 5)
     assert len(np.unique(g.hit_id)) >= 6 and g.stats.rays_reflect > 0
     assert_batches_match(w, n=1200, seed=seed, center=(0., 1., -1.), radius=10.)
+    if seed == 0:   # a larger frame afterwards: the per-lane slab grows with the batch, the grid reaches its 256 workgroups
+        big = Camera(224, 144, PI / 3.)
+        big.transform = cam.transform
+        assert_image_parity(w, big, 4)
+        assert_image_parity(w, cam, 5)
     cam.transform = projective(cam.transform)        # and a projective camera on top
     assert_image_parity(w, cam, 3)
     cam.transform = scale(1., 0., 1.)                # and one without an inverse
