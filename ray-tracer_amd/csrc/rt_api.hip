@@ -523,14 +523,15 @@ void fill_stats(rt_scene* s, int D, rt_stats* stats) {
 
 // ---- overflow fix-up ---------------------------------------------------------------------------------------------
 // Capacities of the BIG variants' lists by round (CSG pending intersections, n1/n2 / intersect_world list entries) and
-// the grid they run with; the arena is lanes x (csg * 28 + list * 16) bytes, about 1.5 GB in either round.
+// the grid they run with; the arena is lanes x (csg * 32 + list * 16) bytes, about 1.6 GB in either round.  CSG trees may nest
+// as deep as the CSG list is long (one mark per open node, kept in the slab too).
 struct ArenaRound { int csg_cap, list_cap, wgs; };
 constexpr ArenaRound ARENA_ROUNDS[] = {{1024, 4096, 16}, {8192, 32768, 2}};
 constexpr int N_ARENA_ROUNDS = int(sizeof ARENA_ROUNDS / sizeof ARENA_ROUNDS[0]);
 
 int ensure_arena(rt_scene* s, int round) {
     const ArenaRound& a = ARENA_ROUNDS[round];
-    const long long lane_bytes = (long long)a.csg_cap * 28 + (long long)a.list_cap * 16;
+    const long long lane_bytes = (long long)a.csg_cap * 32 + (long long)a.list_cap * 16;
     int rc = grow(s->arena, size_t(lane_bytes) * size_t(a.wgs) * TBLOCK);
     if (rc != RT_OK) return rc;
     s->ds.arena = static_cast<char*>(s->arena.p);

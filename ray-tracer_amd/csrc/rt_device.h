@@ -26,7 +26,7 @@ constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
 constexpr int CSG_DEPTH = 8;      // nested CSG levels
-constexpr int CSG_DEPTH_BIG = 64;  // ... in the overflow (BIG) kernel variants, whose lists live in the HBM arena
+// (the overflow (BIG) kernel variants keep their CSG marks in the HBM arena: as many nested levels as pending entries)
 #ifndef RT_LIST_CAP
 #define RT_LIST_CAP 256
 #endif
@@ -93,7 +93,7 @@ struct DScene {
     double cull_min_dir2;             // ... and whose direction has a squared length of at least this (0: any; see Program)
     // HBM arena of the BIG kernel variants (rt_kernels.hip.h: CsgScratch<true>, arena_list): one slab per lane
     char* arena;
-    long long arena_lane_bytes;       // csg_cap * 28 + list_cap * 16
+    long long arena_lane_bytes;       // csg_cap * 32 + list_cap * 16
     int32_t arena_csg_cap, arena_list_cap;
     int32_t* spill;                   // [3 * deepest tree + 1 - LDS_STACK][spill_lanes] traversal stack entries beyond LDS_STACK
     long long spill_lanes;

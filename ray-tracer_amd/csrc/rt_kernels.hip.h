@@ -781,7 +781,7 @@ template <>
 struct CsgScratch<true> {
     double *t, *u, *v;
     int* key;
-    int seg[CSG_DEPTH_BIG];
+    int* seg;  // one mark per open CSG node, in the slab as well: CSG trees may nest as deep as the slab holds entries
     int n, depth;
     unsigned flags;
     int cap_;
@@ -792,13 +792,14 @@ struct CsgScratch<true> {
         u = t + cap_;
         v = u + cap_;
         key = reinterpret_cast<int*>(v + cap_);
+        seg = key + cap_;
     }
     __device__ __forceinline__ int cap() const { return cap_; }
-    __device__ __forceinline__ int max_depth() const { return CSG_DEPTH_BIG; }
+    __device__ __forceinline__ int max_depth() const { return cap_; }
 };
 // the list part of a lane's arena slab (behind the CSG part): t[list_cap], key[list_cap], containers[list_cap]
 __device__ __forceinline__ char* arena_list(const DScene& S) {
-    return S.arena + ((long long)blockIdx.x * TBLOCK + threadIdx.x) * S.arena_lane_bytes + (long long)S.arena_csg_cap * 28;
+    return S.arena + ((long long)blockIdx.x * TBLOCK + threadIdx.x) * S.arena_lane_bytes + (long long)S.arena_csg_cap * 32;
 }
 
 

@@ -686,6 +686,42 @@ def test_cull_ranges_are_not_trusted_from_very_far_away():
     assert np.array_equal(g_id, o_id) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
 
 
+def test_csg_trees_built_by_a_loop_nest_far_beyond_the_per_lane_depth():
+    """`csg = CSG::new(Union, csg, next)` a hundred times (src/csg.rs:32-51) nests a hundred CSG nodes: the ordinary kernels
+    hold 8 open CSG nodes per lane, the arena variants held 64 until round 3 and now as many as their CSG list is long.
+    A left-deep union of 100 spheres, a right-deep difference chain of 70 cubes and both inside one more CSG, through every
+    path: frame (with and without rt_stats), color_at, lists, shadows — against the oracle, and no overflow flag."""
+    w = World()
+    w.lights.append(Light.point_light((-6., 9., -10.), rt.WHITE))
+    w.objects.append(Shape.plane().set_material(Material(reflective=0.2)))
+    chain = Shape.sphere().set_transform(translate(-6., 1., 0.) * scale(0.5, 0.5, 0.5))
+    for k in range(1, 100):
+        nxt = Shape.sphere().set_transform(translate(-6. + 0.12 * k, 1. + 0.3 * math.sin(0.4 * k), 0.2 * math.cos(0.3 * k)) * scale(0.5, 0.5, 0.5))
+        chain = Shape.csg("union", chain, nxt)
+    chain.set_material(Material(color=(0.8, 0.4, 0.2), reflective=0.1))
+    w.objects.append(chain)
+    tail = Shape.cube().set_transform(translate(0., 3.5, 3.) * scale(0.3, 0.3, 0.3))
+    for k in range(70):
+        big = Shape.cube().set_transform(translate(0., 3.5, 3.) * rotate(0.05 * k, Axis.Y) * scale(2. - 0.02 * k, 2. - 0.02 * k, 2. - 0.02 * k))
+        tail = Shape.csg("difference", big, tail)
+    tail.set_material(Material(color=(0.2, 0.5, 0.9), transparency=0.4, refractive_index=1.2))
+    w.objects.append(Shape.csg("intersection", tail, Shape.sphere().set_transform(translate(0., 3.5, 3.) * scale(2.4, 2.4, 2.4))))
+    cam = Camera(64, 40, PI / 2.5)
+    cam.transform = view_transform((0., 4., -9.), (0., 2., 1.), (0., 1., 0.))
+    g, _ = assert_image_parity(w, cam, 4)
+    assert not g.flags.any() and len(np.unique(g.hit_id)) > 20
+    q = cam.render(w, 4, want_stats=False)
+    assert np.array_equal(q.rgb, g.rgb) and np.array_equal(q.hit_id, g.hit_id) and not q.flags.any()
+    o, d = _random_rays(300, 21, center=(-1., 2., 1.), radius=9.)
+    gc, gt, gi = w.intersect_world_batch(o, d, 64)
+    oc, ot, oi = ob.intersect_world_batch(w, o, d, 64)
+    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi) and gc.max() >= 4
+    g_rgb, g_id, g_fl = w.color_at_batch(o, d, 3)
+    o_rgb, o_id, o_fl = ob.color_at_batch(w, o, d, 3)
+    assert np.array_equal(g_id, o_id) and not g_fl.any() and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+    assert np.array_equal(w.is_shadowed_batch(o), ob.is_shadowed_batch(w, o))
+
+
 def test_cubes_under_cull_ranges_keep_the_hits_the_reference_leaks():
     """Cube::check_axis calls an object-space direction component below EPSILON parallel (src/cube.rs:64-78): with the origin
     between that axis' planes the slab is all of t, so a ray that drifts out of it on the way — by up to EPSILON |t| —
