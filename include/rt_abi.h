@@ -96,7 +96,7 @@ extern "C" {
 #define RT_FLAG_NAN_T 2u         /* a NaN t reached a sort: reference panics in partial_cmp().unwrap()
                                     (src/world.rs:52, src/group.rs:59, src/csg.rs:71)                    */
 #define RT_FLAG_LIST_OVERFLOW 4u /* a bounded device list overflowed even in the library's last resort: the kernels keep
-                                  * 32 pending intersections per CSG subtree (8 nested) and 256 list entries for the n1/n2
+                                  * 32 pending intersections per CSG subtree (128 nested) and 256 list entries for the n1/n2
                                   * walk in per-lane memory; a ray that needs more is traced again — automatically, inside
                                   * the same call — by kernel variants whose lists live in an HBM arena (8192 pending, as many
                                   * nested / 32768).  Only beyond THOSE sizes is the flag ever seen (and the pixel not guaranteed). */

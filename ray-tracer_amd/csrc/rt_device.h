@@ -25,7 +25,7 @@ constexpr int FEED_PARTS = 8;     // chunk-feed counters per traversal kernel, o
 constexpr int FEED_STRIDE = 16;   // in counters (128 bytes)
 constexpr int FEED_ROWS = 64;     // consecutive feed positions are 1/FEED_ROWS of the level apart (see Feed::next)
 constexpr int CSG_CAP = 32;       // per-ray scratch entries while inside CSG subtrees
-constexpr int CSG_DEPTH = 8;      // nested CSG levels
+constexpr int CSG_DEPTH = 128;    // nested CSG levels held per lane (deeper trees: the arena variants)
 // (the overflow (BIG) kernel variants keep their CSG marks in the HBM arena: as many nested levels as pending entries)
 #ifndef RT_LIST_CAP
 #define RT_LIST_CAP 256
