@@ -1232,6 +1232,9 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     s->ds.all_cast_shadow = prog.all_cast_shadow ? 1 : 0;
     s->ds.cull_reach = prog.cull_reach;
     s->ds.cull_min_dir2 = prog.cull_min_dir2;
+    s->ds.far_a = prog.far_a;
+    s->ds.far_b = prog.far_b;
+    s->ds.far_extent = prog.far_extent;
     s->ds.tlas_root = prog.tlas_root;
     s->ds.n_linear = prog.n_linear;
     s->ds.n_lds = int32_t(std::min<size_t>(prog.bvh.size(), size_t(LDS_NODE_CAP)));

@@ -90,6 +90,7 @@ struct DScene {
     int32_t tlas_root;                // BVH4 over the bounded top-level objects (Program::tlas_root), -1: none
     int32_t n_linear;                 // items [0, n_linear) are walked by every ray; the rest only through the top-level tree
     double cull_reach;                // ITEM_CULL ranges are trusted for rays whose origin has max |coordinate| below this
+    double far_a, far_b, far_extent;  // SC_TLAS kernels: box growth (far_a D + far_b) D for a ray that starts D = max|origin| + far_extent away
     double cull_min_dir2;             // ... and whose direction has a squared length of at least this (0: any; see Program)
     // HBM arena of the BIG kernel variants (rt_kernels.hip.h: CsgScratch<true>, arena_list): one slab per lane
     char* arena;

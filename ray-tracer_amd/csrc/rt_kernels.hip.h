@@ -689,9 +689,12 @@ __device__ __forceinline__ void bvh_traverse(const DScene& S, const TravMem& M, 
 // (`trusted` == false) is handed every object, and the object's own ITEM_CULL tests its f64 box once more — against
 // the bound the sink has by then — before anything is intersected.
 template <bool COUNT, class Sink>
-__device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 ro, V3 rd, const Sink& sink, bool trusted, int& tsp, Work& w) {
+__device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 ro, V3 rd, const Sink& sink, float inflate, int& tsp, Work& w) {
     const V3 inv = mk(slab_rcp(rd.x), slab_rcp(rd.y), slab_rcp(rd.z));
     const RayF rf = make_rayf(ro, inv);
+    // rays that start beyond the program's reach test every box GROWN by what the reference's arithmetic can leak from that
+    // far away (traverse: `inflate`); a wavefront without such a ray skips the adjustment
+    const bool any_inflate = __ballot(inflate > 0.f) != 0;
     while (tsp > 0) {
         const int cur = stack_pop(M, --tsp);
         if (cur < 0) return ~cur;
@@ -721,6 +724,12 @@ __device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 r
         }
         bump<COUNT>(w.bvh_nodes);
         bump<COUNT>(w.box, 4);
+        if (any_inflate) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { lo[a][c] -= inflate; hi[a][c] += inflate; }
+        }
         const double tlo = sink.lo(), thi = sink.hi();
         float tn[4];
         if (rf.ok) {
@@ -728,7 +737,7 @@ __device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 r
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float t;
-                bool hit = (bvh_box_f32<false>(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t) | !trusted) &
+                bool hit = bvh_box_f32<false>(lo[0][c], lo[1][c], lo[2][c], hi[0][c], hi[1][c], hi[2][c], rf, tlo_f, thi_f, t) &
                            (ch[c] != INT32_MIN);
                 tn[c] = hit ? (t == t ? t : -INFINITY) : INFINITY;
                 if (!hit) ch[c] = INT32_MIN;
@@ -737,8 +746,8 @@ __device__ __forceinline__ int tlas_next(const DScene& S, const TravMem& M, V3 r
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 double t;
-                bool hit = (bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c], (double)hi[2][c],
-                                    ro, inv, tlo, thi, t) | !trusted) & (ch[c] != INT32_MIN);
+                bool hit = bvh_box((double)lo[0][c], (double)lo[1][c], (double)lo[2][c], (double)hi[0][c], (double)hi[1][c], (double)hi[2][c],
+                                   ro, inv, tlo, thi, t) & (ch[c] != INT32_MIN);
                 tn[c] = hit ? (t == t ? (float)t : -INFINITY) : INFINITY;
                 if (!hit) ch[c] = INT32_MIN;
             }
@@ -860,8 +869,23 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     // From very far away the reference's quadratics report tangent hits outside the padded bounds of the ITEM_CULL
     // ranges (rt_program.cpp: WBox::reach): a ray that starts beyond the scene's reach is never culled by them.
     // (the direction's length only matters to scenes with a bounded cube: rt_program.cpp, world_box)
-    const bool cull_trusted = HAS_CULL && fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) < S.cull_reach &&
-                              (S.cull_min_dir2 == 0. || dot(rd, rd) >= S.cull_min_dir2);
+    // (the direction's length only matters to scenes with a bounded cube: rt_program.cpp, world_box)
+    bool cull_trusted = HAS_CULL && fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) < S.cull_reach &&
+                        (S.cull_min_dir2 == 0. || dot(rd, rd) >= S.cull_min_dir2);
+    // Under a top-level tree a ray from beyond the reach is not simply handed everything: from D away (L-infinity, to anything
+    // bounded) the reference's quadratics leak by at most far_a D^2 and everything else by far_b D (rt_program.cpp: the bounds
+    // behind Program::far_a / far_b), so that ray tests every box grown by (far_a D + far_b) D — a fraction of a unit from
+    // thousands of units away.  Only a ray whose direction is too short for a bounded cube, or that is not finite, is left
+    // with no culling at all (`far_lane`, below).  (Kernels without a tree keep the plain rule, and their code.)
+    double inflate = 0.;
+    bool cull_inflated = false;
+    float inflate_f = 0.f;
+    if (HAS_TLAS && !cull_trusted && (S.cull_min_dir2 == 0. || dot(rd, rd) >= S.cull_min_dir2)) {
+        const double dist = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z)) + S.far_extent;
+        inflate = (S.far_a * dist + S.far_b) * dist;
+        cull_inflated = inflate > 0. && inflate < 1e30;  // (NaN: false)
+        inflate_f = cull_inflated ? __double2float_ru(inflate) : 0.f;
+    }
     const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
     const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
     const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);
@@ -880,6 +904,8 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     int range_end = HAS_TLAS ? S.n_linear : n_items;
     int tsp = 0, cand = -1;
     bool mine = false;  // this lane asked for the range the wavefront is in
+    bool swept = false;
+    const bool far_lane = tlas && alive && !cull_trusted && !cull_inflated;
     if (tlas && alive) {
         stack_push(M, 0, S.tlas_root);
         tsp = 1;
@@ -891,13 +917,26 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
         bool job = false, job_full = false, items_round = true;
         V3 job_o = ro, job_d = rd, job_inv = rd;
         int job_root = 0, job_base = 0;
+        if (HAS_TLAS && i >= range_end && tlas && !swept) {
+            // Rays that may not trust the boxes (they start beyond the program's reach, or their direction is too short for
+            // a bounded cube: cull_trusted) get ONE wavefront-uniform pass over every bounded object, boxes ignored, before the
+            // tree is asked anything — handing such a ray its objects one dispatcher round each cost a world of two thousand
+            // spheres 2.5 ms per 64 shadow rays that start near the horizon of its floor.
+            swept = true;
+            if (__ballot(far_lane) != 0) {
+                mine = false;
+                i = S.n_linear;
+                range_end = n_items;
+                until = far_lane ? i : n_items;
+            }
+        }
         if (HAS_TLAS && i >= range_end) {
             if (!tlas) break;
             if (mine) cand = -1;  // that range is done
             mine = false;
-            if (!alive) cand = 0x7fffffff;
+            if (!alive || far_lane) cand = 0x7fffffff;
             if (cand != 0x7fffffff && sink.done()) cand = 0x7fffffff;
-            if (cand < 0) cand = tlas_next<COUNT>(S, M, ro, rd, sink, cull_trusted, tsp, w);
+            if (cand < 0) cand = tlas_next<COUNT>(S, M, ro, rd, sink, inflate_f, tsp, w);
             const bool instance = cand != 0x7fffffff && (cand & TLAS_INSTANCE);
             const int header = instance ? (cand & ~TLAS_INSTANCE) - 1 : cand;  // an instance's ITEM_CULL sits in front of its ITEM_MESH
             const int lowest = wave_min_i32(header);
@@ -912,7 +951,8 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                 items_round = false;
                 if (instance) {
                     const Item* __restrict__ q = S.items + (cand & ~TLAS_INSTANCE);  // per-lane fetch
-                    const int m_node = q->node, m_root = q->a, m_box = q->b, m_len = q->chain_len, m_x0 = q->x0, m_x1 = q->x1, m_chain = q->chain;
+                    const int m_type = q->type, m_node = q->node, m_root = q->a, m_box = q->b, m_len = q->chain_len, m_x0 = q->x0, m_x1 = q->x1,
+                              m_chain = q->chain;
                     V3 o = ro, d = rd;
                     for (int k = 0; k < m_len; ++k) {  // Ray::transform per level, outermost first (src/shape.rs:75-76)
                         const int x = k == 0 ? m_x0 : k == 1 ? m_x1 : S.chain_pool[m_chain + 1 + k];
@@ -920,12 +960,25 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                         o = xf_point(m, o);
                         d = xf_vector(m, d);
                     }
-                    if (COUNT) { w.xforms += m_len; ++w.box; }
-                    const double* __restrict__ mb = S.mesh_box + (size_t)m_box * 6;
-                    const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
-                    double tnear;
-                    job = bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, sink.lo_mesh(), sink.hi(), tnear);
-                    job_o = o; job_d = d; job_inv = inv; job_root = m_root; job_base = m_node;
+                    if (COUNT) w.xforms += m_len;
+                    if (m_type == ITEM_MESH) {
+                        bump<COUNT>(w.box);
+                        const double* __restrict__ mb = S.mesh_box + (size_t)m_box * 6;
+                        const V3 inv = mk(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+                        double tnear;
+                        job = bvh_box(mb[0], mb[1], mb[2], mb[3], mb[4], mb[5], o, inv, sink.lo_mesh(), sink.hi(), tnear);
+                        job_o = o; job_d = d; job_inv = inv; job_root = m_root; job_base = m_node;
+                    } else {
+                        // a bounded primitive that is a top-level object of its own (sphere, cube, truncated cylinder): every lane
+                        // intersects the one ITS ray reached, here and now — a world of two thousand spheres otherwise has the
+                        // wavefront visit them one by one for a lane or two each
+                        const int m_kind = q->kind, m_closed = q->op;
+                        const double m_p0 = q->p0, m_p1 = q->p1;
+                        auto lane_out = [&](double t, int k, double u, double v, int uv) { out(t, m_node * 4 + k, u, v, uv); };
+                        if (m_kind == RT_SPHERE) { bump<COUNT>(w.prim[0]); isect_sphere(o, d, lane_out); }
+                        else if (m_kind == RT_CUBE) { bump<COUNT>(w.prim[2]); isect_cube(o, d, lane_out); }
+                        else { bump<COUNT>(w.prim[3]); isect_cylinder(o, d, m_p0, m_p1, m_closed != 0, lane_out); }
+                    }
                     cand = -1;
                 }
             }
@@ -1018,7 +1071,14 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
                 const V3 inv_world = mk(slab_rcp(rd.x), slab_rcp(rd.y), slab_rcp(rd.z));
                 double tnear;
                 bump<COUNT>(w.box);
-                if (cull_trusted && !bvh_box(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], ro, inv_world, sink.lo(), sink.hi(), tnear)) until = it.skip;
+                if (HAS_TLAS) {
+                    const double g = cull_inflated ? inflate : 0.;
+                    if ((cull_trusted || cull_inflated) &&
+                        !bvh_box(cb[0] - g, cb[1] - g, cb[2] - g, cb[3] + g, cb[4] + g, cb[5] + g, ro, inv_world, sink.lo(), sink.hi(), tnear))
+                        until = it.skip;
+                } else {
+                    if (cull_trusted && !bvh_box(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], ro, inv_world, sink.lo(), sink.hi(), tnear)) until = it.skip;
+                }
             }
             if (__ballot(i >= until) == 0) i = wave_min_i32(until);  // nobody needs the range: jump, uniformly
             continue;

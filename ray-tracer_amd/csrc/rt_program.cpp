@@ -482,6 +482,37 @@ struct Compiler {
         }
         return prod > 0. && std::isfinite(prod) ? 1. / prod : 0.;
     }
+    double chain_max_scale(const std::vector<int32_t>& chain) {  // upper bound of the largest singular value of the forward chain
+        double prod = 1.;
+        for (int32_t x : chain) {
+            const std::vector<double>& fm = forward_of(x);
+            if (fm.empty()) return INF;
+            double f2 = 0.;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) f2 += fm[size_t(4 * r + c)] * fm[size_t(4 * r + c)];
+            prod *= std::sqrt(f2);
+        }
+        return std::isfinite(prod) ? prod : INF;
+    }
+    // what a leaf under `chain` can leak beyond its box for a ray from D away (Program::far_a / far_b); kind: 0 quadratic
+    // (sphere, cylinder), 1 cube, 2 triangles
+    void note_far_leak(const std::vector<int32_t>& chain, int kind) {
+        constexpr double EPS64 = 1.1102230246251565e-16, SAFETY = 8.;
+        const double smin = chain_min_scale(chain), smax = chain_max_scale(chain);
+        if (!(smin > 0.) || !std::isfinite(smax)) { p.far_a = INF; p.far_b = INF; return; }
+        const double ratio = smax / smin;
+        if (kind == 0) {
+            // |o_obj| <= sqrt(3) D / smin radii; disc = b^2 - 4ac turns non-negative up to 2 eps R^2 outside the unit shape;
+            // a near-tangent root is off by sqrt(8 eps) R / |d| in t, i.e. 3e-8 R object units along the ray
+            p.far_a = std::max(p.far_a, SAFETY * 2. * EPS64 * 3. * smax / (smin * smin));
+            p.far_b = std::max(p.far_b, SAFETY * 4e-8 * 1.7320508075688774 * ratio);
+        } else if (kind == 1) {
+            // EPSILON |t| object units with |t| <= 2 sqrt(3) D for directions at least 1/2 long
+            p.far_b = std::max(p.far_b, SAFETY * 2. * 1.7320508075688774 * 0.00001 * smax);
+        } else {
+            p.far_b = std::max(p.far_b, SAFETY * 1e3 * EPS64 * ratio);  // u, v lose ~eps |o| / edge: lateral error ~eps |o|, x 1e3
+        }
+    }
     // object-space box -> world, through the non-identity transforms `chain` (outermost first); `size`: the object-space
     // length the leaf's arithmetic error is relative to (1 for the unit shapes)
     WBox to_world(const double* lo, const double* hi, const std::vector<int32_t>& chain, double size = 1.) {
@@ -514,7 +545,11 @@ struct Compiler {
         const int32_t kind = d.node_kind[node];
         const double unit_lo[3] = {-1., -1., -1.}, unit_hi[3] = {1., 1., 1.};
         switch (kind) {
-            case RT_SPHERE: return to_world(unit_lo, unit_hi, chain);
+            // (sphere and cylinder: `size` 10 = trusted from 1e4 object radii.  A quadratic computed from an origin R radii away
+            // reports tangent hits up to ~2 eps R^2 outside the unit shape: 2e-8 at 1e4, a tenth of the boxes' 1e-7 padding of the
+            // object's own extent.  Round 2 allowed 1e3, which left a world of small spheres on a large floor with most of
+            // its shadow rays untrusted.)
+            case RT_SPHERE: note_far_leak(chain, 0); return to_world(unit_lo, unit_hi, chain, 10.);
             case RT_CUBE: {
                 // check_axis treats an object-space direction component below EPSILON as parallel (src/cube.rs:64-78): that
                 // axis' slab is then all of t when the ORIGIN lies between its planes, so the ray may drift out of the slab
@@ -535,7 +570,7 @@ struct Compiler {
                 // stays unbounded, as every cube was before
                 for (int k = 0; k < 3 && w.bounded; ++k)
                     if (std::max(std::fabs(w.lo[k]), std::fabs(w.hi[k])) > CUBE_REACH / 2.) w.bounded = false;
-                if (w.bounded) p.cull_min_dir2 = 0.25;
+                if (w.bounded) { p.cull_min_dir2 = 0.25; note_far_leak(chain, 1); }
                 return w;
             }
             case RT_PLANE: { WBox w; w.bounded = false; return w; }
@@ -552,9 +587,11 @@ struct Compiler {
                 // the caps accept x^2 + z^2 < 1 or within EPSILON of 1 (src/cylinder.rs:96-101): radius^2 up to 1 + 1e-5
                 const double r = std::sqrt(1. + 2e-5);
                 const double lo[3] = {-r, std::min(mn, mx), -r}, hi[3] = {r, std::max(mn, mx), r};
-                return to_world(lo, hi, chain);
+                note_far_leak(chain, 0);
+                return to_world(lo, hi, chain, 10.);
             }
             case RT_TRIANGLE: case RT_SMOOTH_TRIANGLE: {
+                note_far_leak(chain, 2);
                 const int32_t t = d.node_param[node];
                 double lo[3], hi[3];
                 for (int k = 0; k < 3; ++k) {
@@ -585,7 +622,7 @@ struct Compiler {
                     }
                 }
                 // (triangles: see RT_TRIANGLE above; the mesh's own extent is the scale its padding is relative to)
-                if (any_plain) w.add(to_world(lo, hi, chain, 1e3 * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]))));
+                if (any_plain) { note_far_leak(chain, 2); w.add(to_world(lo, hi, chain, 1e3 * std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])))); }
                 return w;
             }
             default: {  // CSG: whatever survives the filter lies on an operand
@@ -625,6 +662,7 @@ struct Compiler {
             // into one bound on the origin's largest |coordinate| for the whole program
             double far_plane = 0.;
             for (int k = 0; k < 6; ++k) far_plane = std::max(far_plane, std::fabs(b[k]));
+            p.far_extent = std::max(p.far_extent, far_plane);
             const double r = std::max(0., all.reach - far_plane);
             p.cull_reach = p.has_cull ? std::min(p.cull_reach, r) : r;
             cull = int32_t(p.items.size());
@@ -668,8 +706,15 @@ struct Compiler {
             // an object that is nothing but one mesh under its transforms — [ITEM_CULL, ITEM_MESH) — is an INSTANCE: the
             // link names the ITEM_MESH itself and the kernels let every lane walk its own instance at the same time
             // (rt_kernels.hip.h: traverse), instead of the wavefront visiting the objects one after the other
+            // ... and so is a bounded primitive that is an object of its own, [ITEM_CULL, ITEM_LEAF): each lane intersects the
+            // sphere, cube or cylinder its own ray reached
             const int32_t h = tlas_header[lo];
-            const bool instance = RT_TLAS_PER_LANE && opts.tlas_instances && p.items[size_t(h)].skip == h + 2 && p.items[size_t(h) + 1].type == ITEM_MESH;
+            bool instance = false;
+            if (RT_TLAS_PER_LANE && opts.tlas_instances && p.items[size_t(h)].skip == h + 2) {
+                const Item& body = p.items[size_t(h) + 1];
+                instance = body.type == ITEM_MESH ||
+                           (body.type == ITEM_LEAF && (body.kind == RT_SPHERE || body.kind == RT_CUBE || body.kind == RT_CYLINDER));
+            }
             return instance ? ~((h + 1) | TLAS_INSTANCE) : ~h;
         }
         int axis = 0;

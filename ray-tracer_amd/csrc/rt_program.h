@@ -95,6 +95,11 @@ struct Program {
     int32_t tlas_levels = 0;           // BVH4 levels of the top-level tree (its share of the traversal stack)
     bool has_cull = false;             // the program has ITEM_CULL ranges
     double cull_reach = 0.;            // ... trusted for rays whose origin has max |coordinate| below this (WBox::reach)
+    // Rays from beyond the reach, under a top-level tree: every box is grown by (far_a D + far_b) D, D = the L-infinity distance
+    // the origin can have from anything bounded (max |origin coordinate| + far_extent).  far_a bounds the quadratics' leak
+    // (2 eps R^2 object units from R radii away), far_b the linear ones (a cube's EPSILON |t|, the t error of a near-tangent
+    // root, Moller-Trumbore's u, v); both carry a safety factor of 8 (rt_program.cpp: world_box).
+    double far_a = 0., far_b = 0., far_extent = 0.;
     double cull_min_dir2 = 0.;         // ... and whose direction is at least this long, squared (0.25 once a cube is bounded: its
                                        // padding covers the reference's leak only up to a parameter |t| of CUBE_PAD / EPSILON)
     bool has_smooth = false;

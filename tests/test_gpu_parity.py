@@ -659,31 +659,43 @@ def test_passive_mesh_triangles_in_the_n1_n2_walk_change_nothing(monkeypatch):
 def test_cull_ranges_are_not_trusted_from_very_far_away():
     """from ~1e5 radii away the reference's quadratic (c = o.o - 1, b^2 - 4ac) reports tangent hits a few 1e-7
     outside the unit sphere, further than the padding of the world-space cull boxes.  Rays aimed at the silhouette
-    +-1e-6 of small spheres in a world of eight bounded objects, from 1e5 away: lists equal to the oracle's."""
-    w = World()
-    w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
-    centres = [(2. * k - 7., 0.3 * k, 1.5 * (k % 3)) for k in range(8)]
-    for k, c in enumerate(centres):
-        sh = Shape.sphere() if k % 2 == 0 else Shape.cylinder().set_minimum(-1.).set_maximum(1.).set_closed(True)
-        w.objects.append(sh.set_transform(translate(*c)))
-    rng = np.random.default_rng(3)
-    o, d = [], []
-    for c in centres:
-        for _ in range(400):
-            u = rng.normal(size=3); u /= np.linalg.norm(u)
-            origin = np.array(c) + 1e5 * u
-            v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
-            target = np.array(c) + v * (1. + rng.uniform(-1e-6, 1e-6))     # a point on the silhouette seen from `origin`
-            dirn = target - origin
-            o.append(origin); d.append(dirn / np.linalg.norm(dirn))
-    o, d = np.array(o), np.array(d)
-    gc, gt, gi = w.intersect_world_batch(o, d, 16)
-    oc, ot, oi = ob.intersect_world_batch(w, o, d, 16)
-    assert (oc > 0).sum() > 200 and (oc == 0).sum() > 200          # the sample straddles the silhouettes
-    assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
-    g_rgb, g_id, _ = w.color_at_batch(o, d, 2)
-    o_rgb, o_id, _ = ob.color_at_batch(w, o, d, 2)
-    assert np.array_equal(g_id, o_id) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+    +-1e-6 of small spheres and cylinders, from 3e3 to 1e6 radii away: lists equal to the oracle's — in a world of eight
+    bounded objects (nested ranges: beyond the reach they are ignored) and in one of eighty (top-level tree: beyond the
+    reach every box is grown by what the arithmetic can leak from that far, rt_program.cpp: note_far_leak)."""
+    for n_objects in (8, 80):
+        w = World()
+        w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
+        if n_objects > 8:
+            w.objects.append(Shape.plane().set_transform(translate(0., -3., 0.)))
+        centres = [(2. * (k % 10) - 7., 0.3 * (k % 7) + 2. * (k // 40), 1.5 * (k % 3) + 3. * ((k // 10) % 4)) for k in range(n_objects)]
+        radii = [(1., 0.3, 0.08, 2.)[k % 4] if n_objects > 8 else 1. for k in range(n_objects)]
+        for k, (c, r) in enumerate(zip(centres, radii)):
+            sh = Shape.sphere() if k % 2 == 0 else Shape.cylinder().set_minimum(-1.).set_maximum(1.).set_closed(True)
+            w.objects.append(sh.set_transform(translate(*c) * scale(r, r, r)))
+        rng = np.random.default_rng(3)
+        o, d = [], []
+        for c, r in list(zip(centres, radii))[:16]:
+            for k in range(240):
+                u = rng.normal(size=3); u /= np.linalg.norm(u)
+                # 3e3 and 9e3 radii: inside the reach round 3 allows (1e4 radii, where the quadratic's leak is a tenth of the
+                # padding); 1e5 and 1e6: beyond it
+                origin = np.array(c) + (1e5, 3e3, 9e3, 1e6)[k % 4] * r * u
+                v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+                target = np.array(c) + v * r * (1. + rng.uniform(-1e-6, 1e-6))     # a point on the silhouette seen from `origin`
+                dirn = target - origin
+                o.append(origin); d.append(dirn / np.linalg.norm(dirn))
+        o, d = np.array(o), np.array(d)
+        gc, gt, gi = w.intersect_world_batch(o, d, 16)
+        oc, ot, oi = ob.intersect_world_batch(w, o, d, 16)
+        if n_objects == 8:
+            assert (oc > 0).sum() > 200 and (oc == 0).sum() > 200      # the sample straddles the silhouettes
+        assert np.array_equal(gc, oc) and np.array_equal(gt, ot) and np.array_equal(gi, oi)
+        g_rgb, g_id, _ = w.color_at_batch(o, d, 2)
+        o_rgb, o_id, _ = ob.color_at_batch(w, o, d, 2)
+        assert np.array_equal(g_id, o_id) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+        # shadow rays from far out on the floor, towards the light past everything
+        far = np.stack([rng.uniform(-2e4, 2e4, 600), np.full(600, -3. + 1e-5), rng.uniform(-2e4, 2e4, 600)], axis=1)
+        assert np.array_equal(w.is_shadowed_batch(far), ob.is_shadowed_batch(w, far))
 
 
 def test_csg_trees_built_by_a_loop_nest_far_beyond_the_per_lane_depth():
