@@ -37,7 +37,37 @@ def cases():
     for k in range(6): w.lights.append(Light.point_light((3. * k - 8., 9., -6.), (0.2, 0.2, 0.2)))
     w.objects += spheres(200, rng); yield "200 spheres, 7 lights", w
 
-for name, w in cases():
+def more_cases():
+    rng = np.random.RandomState(9)
+    w = base()
+    for k in range(500):
+        h = Shape.hexagon().set_transform(translate(rng.uniform(-9, 9), rng.uniform(0.3, 5), rng.uniform(-3, 12)) * rotate(rng.uniform(0, 3), Axis.X) * scale(0.4, 0.4, 0.4))
+        w.objects.append(h)
+    yield "500 hexagon groups (6 x (sphere + cylinder) each)", w
+    w = base()
+    for k in range(300):
+        c = (rng.uniform(-9, 9), rng.uniform(0.3, 5), rng.uniform(-3, 12))
+        a = Shape.cube().set_transform(translate(*c) * scale(0.4, 0.4, 0.4))
+        b = Shape.sphere().set_transform(translate(*c) * scale(0.5, 0.5, 0.5))
+        w.objects.append(Shape.csg("difference", a, b))
+    yield "300 CSG objects (cube - sphere)", w
+    import scenes
+    w = base()
+    t, _ = rt.obj_to_group(scenes.read_asset("teapot.obj"))
+    t.set_transform(translate(0., 0., 2.) * scale(1.2, 1.2, 1.2))
+    w.objects.append(Shape.csg("difference", t, Shape.sphere().set_transform(translate(0., 1.5, 0.5) * scale(1.6, 1.6, 1.6))))
+    yield "difference(teapot mesh, sphere)", w
+    w = base()
+    for k in range(1000):
+        g = Shape.group().set_transform(translate(rng.uniform(-9, 9), rng.uniform(0.3, 5), rng.uniform(-3, 12)))
+        g.add_child(Shape.sphere().set_transform(scale(0.25, 0.25, 0.25)))
+        g.add_child(Shape.cube().set_transform(translate(0.3, 0., 0.) * scale(0.15, 0.15, 0.15)))
+        w.objects.append(g)
+    yield "1000 groups of two primitives", w
+
+
+import itertools
+for name, w in itertools.chain(cases(), more_cases()):
     cam = Camera(960, 540, math.pi / 2.5)
     cam.transform = view_transform((0., 4., -12.), (0., 1.5, 2.), (0., 1., 0.))
     t0 = time.perf_counter()
