@@ -192,7 +192,7 @@ def test_random_worlds_on_every_render_path(seed, monkeypatch):
     size, depth, stride = (1100, 640), 4, 23
     world, cam = builder(seed, *size)
     a = cam.render(world, depth)
-    for _ in range(2):
+    for _ in range(3):   # plain enqueue, graph capture, graph replay
         assert _same_image(a, cam.render(world, depth, want_stats=False))
     cam2 = rt.Camera(size[0], size[1], 0.9)
     cam2.transform = rt.view_transform((9. * math.cos(seed), 4., 9. * math.sin(seed)), (0., 0.5, 0.), (0., 1., 0.))

@@ -430,8 +430,9 @@ def test_full_size_properties_c4_and_c5():
         assert not a.rgb[-1].any() and not a.rgb[:, -1].any()
         assert a.stats.rays_primary == (wd - 1) * (ht - 1)
         assert a.stats.rays_shadow == a.stats.shaded_nodes * len(w.lights)
-        b = cam.render(w, depth, want_stats=False)
-        assert np.array_equal(a.rgb, b.rgb, equal_nan=True) and np.array_equal(a.hit_id, b.hit_id) and np.array_equal(a.flags, b.flags)
+        for _ in range(3):   # enqueued whole; captured as a graph (second sighting of its key); replayed
+            b = cam.render(w, depth, want_stats=False)
+            assert np.array_equal(a.rgb, b.rgb, equal_nan=True) and np.array_equal(a.hit_id, b.hit_id) and np.array_equal(a.flags, b.flags)
         o = ob.render(w, cam, depth, stride=stride)
         ys, xs = np.mgrid[0:ht - 1:stride, 0:wd - 1:stride]
         assert np.array_equal(a.hit_id[ys, xs], o.hit_id[ys, xs])
@@ -459,8 +460,9 @@ def test_c5_at_the_surveys_scale_and_at_the_benchmarked_grid():
         assert np.array_equal(a.hit_id[ys, xs], o.hit_id[ys, xs])
         assert np.array_equal(a.flags[ys, xs], o.flags[ys, xs])
         assert float(np.abs(a.rgb[ys, xs] - o.rgb[ys, xs]).max()) < COLOR_TOL
-        b = cam.render(w, 8, want_stats=False)      # graph-replayed path
-        assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.hit_id, b.hit_id)
+        for _ in range(3):                          # plain enqueue, graph capture, graph replay
+            b = cam.render(w, 8, want_stats=False)
+            assert np.array_equal(a.rgb, b.rgb) and np.array_equal(a.hit_id, b.hit_id)
         del a, b, o
         w.invalidate()
 
@@ -580,7 +582,7 @@ def test_top_level_tree_changes_nothing(monkeypatch):
         assert np.array_equal(np.where(tree.hit_id > 0, tree.hit_id - shift, 0), ranges.hit_id)
         assert np.array_equal(tree.rgb, ranges.rgb, equal_nan=True) and np.array_equal(tree.flags, ranges.flags)
         assert tree.stats.total_rays == ranges.stats.total_rays
-        for _ in range(2):   # and the graph-replayed frame (no rt_stats)
+        for _ in range(3):   # and the captured, then replayed, frame graph (no rt_stats; a key is captured the second time it is seen)
             again = cam1.render(w1, depth, want_stats=False)
             assert np.array_equal(again.rgb, tree.rgb, equal_nan=True) and np.array_equal(again.hit_id, tree.hit_id)
     for seed in range(3):
@@ -961,12 +963,12 @@ def test_rays_made_by_k_trace_equal_the_rays_k_spawn_writes(monkeypatch):
         w1, cam1 = builder(*size)
         first = cam1.render(w1, depth)          # level-by-level walk (sizes the queues)
         again = cam1.render(w1, depth)          # whole frame enqueued at once
-        replays = [cam1.render(w1, depth, want_stats=False) for _ in range(2)]  # captured as a graph, replayed
+        replays = [cam1.render(w1, depth, want_stats=False) for _ in range(3)]  # plain, captured as a graph, replayed
         monkeypatch.setenv("RT_AMD_FUSE_SPAWN", "0")
         w0, cam0 = builder(*size)
         plain = cam0.render(w0, depth)
         plain_again = cam0.render(w0, depth)
-        plain_replays = [cam0.render(w0, depth, want_stats=False) for _ in range(2)]
+        plain_replays = [cam0.render(w0, depth, want_stats=False) for _ in range(3)]
         monkeypatch.delenv("RT_AMD_FUSE_SPAWN")
         shift = int(first.hit_id[first.hit_id > 0].min()) - int(plain.hit_id[plain.hit_id > 0].min())
         for a, b in ((first, plain), (again, plain_again), (again, first)):
@@ -1203,7 +1205,7 @@ def test_render_multi_equals_rt_render(devices):
         ms = rt.MultiScene(w, devices)
         assert rt.lib.rt_scene_gpu_count(ms.h) == len(devices)
         assert ms.gather_kind == (0 if len(devices) == 1 else 2)
-        for _ in range(2):   # twice: the second frame replays graphs on every replica
+        for _ in range(3):   # three times: the third frame replays graphs on every replica
             img = ms.render(cam, depth, want_quantised=True)
             assert np.array_equal(img.rgb, ref.rgb, equal_nan=True)
             assert np.array_equal(img.hit_id, ref.hit_id) and np.array_equal(img.flags, ref.flags)
@@ -1298,7 +1300,7 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
                 assert np.array_equal(img.hit_id, ref.hit_id) and np.array_equal(img.rgb, ref.rgb) and np.array_equal(img.flags, ref.flags), kw
                 cd = cam.desc()
                 opts = rt.RenderOpts(max_depth=depth, rank=0, n_ranks=1, want_counters=0, stream=None)
-                for _ in range(2):  # rt_render without rt_stats: the second frame replays the graph where there is one
+                for _ in range(3):  # rt_render without rt_stats: the third frame replays the graph where there is one
                     rgb, ids = np.zeros_like(ref.rgb), np.zeros_like(ref.hit_id)
                     rc = rt.lib.rt_render(ms.h, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), ids.ctypes.data_as(rt.c_ip), None, None)
                     assert rc == 0, rt.last_error()
