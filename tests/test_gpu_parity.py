@@ -745,18 +745,21 @@ def test_cubes_under_cull_ranges_keep_the_hits_the_reference_leaks():
     cube sizes away, unit directions and very short ones — must list what the oracle lists, in a world of eight bounded
     objects (cubes of scale 0.5 to 17 among them) and in one where a CSG of cubes and a group of cubes are culled."""
     rng = np.random.default_rng(11)
-    for variant in range(2):
+    for variant in range(3):
         w = World()
         w.lights.append(Light.point_light((-5., 8., -9.), rt.WHITE))
         cubes = []
+        if variant == 2:   # 64 more bounded objects: the world gets a top-level tree, whose kernels give the rays with short
+            for k in range(64):   # directions one linear pass over all objects and grow the boxes for the far ones
+                w.objects.append(Shape.sphere().set_transform(translate(5. * (k % 8) - 20., -6. - 2. * (k // 8), 3. * (k % 5)) * scale(0.6, 0.6, 0.6)))
         for k in range(8):
             s = (0.5, 1., 2., 17., 1.5, 0.8, 3., 1.)[k]
             c = (9. * k - 30., 0.5 * k, 4. * (k % 3))
             cube = Shape.cube().set_transform(translate(*c) * rotate(0.2 * k, Axis.Y) * scale(s, s, s))
             cubes.append((c, s, 0.2 * k))
-            if variant == 1 and k % 4 == 1:
+            if variant >= 1 and k % 4 == 1:
                 cube = Shape.csg("difference", cube, Shape.cube().set_transform(translate(c[0], c[1] + 0.5 * s, c[2]) * scale(s, s, s)))
-            elif variant == 1 and k % 4 == 2:
+            elif variant >= 1 and k % 4 == 2:
                 g = Shape.group()
                 g.add_child(cube)
                 cube = g
