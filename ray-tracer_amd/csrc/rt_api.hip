@@ -1132,6 +1132,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     popts.share_meshes = knobs.share_meshes;
     popts.top_level_tree = knobs.tlas;
     popts.tlas_instances = knobs.tlas_instances;
+    if (const char* e = std::getenv("RT_AMD_TLAS_MIN")) popts.tlas_min_objects = std::atoi(e);  // measurement aid only
     popts.verbose = knobs.verbose;
     const auto t_create0 = std::chrono::steady_clock::now();
     int rc = compile_program(*desc, prog, err, popts);

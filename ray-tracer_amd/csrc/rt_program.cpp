@@ -1011,7 +1011,49 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
             if (wb.bounded && wb.lo[0] <= wb.hi[0]) bounded.emplace_back(n, wb);
             else c.emit(n, {});
         }
-    if (opts.cull_ranges && opts.top_level_tree && bounded.size() >= size_t(TLAS_MIN_OBJECTS)) c.emit_tlas(bounded);
+    // From TLAS_MIN_OBJECTS bounded objects on, the tree; from TLAS_MIN_INSTANCES on already when EVERY bounded object is one a
+    // lane handles by itself (a lone sphere / cube / cylinder, or a group that is nothing but one mesh) and the scene has no
+    // CSG (the tree kernels with CSG code are the heaviest variants).  Measured, ranges / tree, ms per frame: 32 teapot
+    // instances scattered at random, 960x540: 3.57 / 1.88 (64: 5.58 / 2.73); 32 spheres: 0.81 / 0.68 (96: 1.59 / 1.03); but a
+    // regular grid of 16 teapots at 8K 13.1 / 14.3, of 36: 15.5 / 15.6; C5 at grid 4 (16 teapots + 16 two-triangle groups,
+    // which the wavefront visits in turn) 14.1 / 15.3; C4 (9 objects, CSG and a hexagon among them) 5.4 / 8.3.
+    size_t tlas_from = size_t(TLAS_MIN_OBJECTS);
+    if (bounded.size() >= size_t(TLAS_MIN_INSTANCES) && bounded.size() < tlas_from) {
+        bool all_by_lane = true;
+        for (int32_t n = 0; n < d.n_nodes && all_by_lane; ++n) all_by_lane = d.node_kind[n] != RT_CSG;
+        for (const auto& b : bounded) {
+            if (!all_by_lane) break;
+            const int32_t n = b.first, k = d.node_kind[n];
+            if (k == RT_SPHERE || k == RT_CUBE || k == RT_CYLINDER) continue;
+            // a group without a gate (infinite or empty box: see emit) that holds nothing but triangles — directly, or inside
+            // one more such group, the way obj_to_group wraps an OBJ's default group — is emitted as one ITEM_MESH
+            bool one_mesh = false;
+            for (int32_t g = n; d.node_kind[g] == RT_GROUP;) {
+                const double* box = d.group_box + size_t(d.node_param[g]) * 6;
+                bool infinite = true, empty = true;
+                for (int a = 0; a < 3; ++a) {
+                    infinite = infinite && box[a] == -INF && box[3 + a] == INF;
+                    empty = empty && box[a] == INF && box[3 + a] == -INF;
+                }
+                if (!infinite && !empty) break;
+                const int32_t first = g + 1, end = d.node_subtree_end[g];
+                if (first >= end) break;
+                if (d.node_subtree_end[first] == end && d.node_kind[first] == RT_GROUP) { g = first; continue; }
+                size_t tris = 0;
+                bool all_tris = true;
+                for (int32_t ch = first; ch < end && all_tris; ch = d.node_subtree_end[ch]) {
+                    all_tris = Compiler::is_tri_kind(d.node_kind[ch]) && d.node_xform[ch] == 0;
+                    ++tris;
+                }
+                one_mesh = all_tris && tris >= size_t(MESH_MIN_TRIANGLES);
+                break;
+            }
+            all_by_lane = one_mesh;
+        }
+        if (all_by_lane) tlas_from = size_t(TLAS_MIN_INSTANCES);
+    }
+    if (opts.tlas_min_objects > 0) tlas_from = size_t(opts.tlas_min_objects);
+    if (opts.cull_ranges && opts.top_level_tree && bounded.size() >= tlas_from) c.emit_tlas(bounded);
     else c.emit_culled(bounded, 0, bounded.size());
     if (out.tlas_root < 0) out.n_linear = int32_t(out.items.size());
     for (int32_t n = 0; n < d.n_nodes; ++n) {

@@ -117,6 +117,7 @@ struct ProgramOpts {
     bool device_bvh = false;
     bool cull_ranges = true;
     bool tlas_instances = true;  // ... whose one-mesh objects are walked per lane (RT_AMD_TLAS=2: left to the wavefront, A/B)
+    int tlas_min_objects = 0;    // > 0: build the tree from this many bounded objects on instead of the library's rule (RT_AMD_TLAS_MIN: A/B)
     bool top_level_tree = true;  // worlds with >= TLAS_MIN_OBJECTS bounded top-level objects get a tree over them (RT_AMD_TLAS=0: A/B)
     bool share_meshes = true;   // groups with identical triangle content take one tree (RT_AMD_SHARE_MESHES=0: A/B)
     bool verbose = false;   // phase times of the compilation on stderr
@@ -144,6 +145,7 @@ constexpr int32_t TLAS_INSTANCE = 1 << 29;  // in a top-level leaf link ~c: c & 
                                             // instance, walked per lane) rather than of an object's ITEM_CULL (walked by the wavefront)
 constexpr int TLAS_MIN_OBJECTS = 64;     // fewer bounded top-level objects: nested ITEM_CULL ranges in program order (measured on C5
                                          // at 8K, ranges / tree: 32 objects 14.3 / 15.9 ms, 72: 17.1 / 17.0, 128: 19.0 / 18.0, 338: 24.8 / 20.5)
+constexpr int TLAS_MIN_INSTANCES = 32;   // ... but already from this many when every one of them is walked per lane (rt_program.cpp: compile_program)
 constexpr int LBVH_MIN_TRIANGLES = 1024; // smaller meshes are always built on the host
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
 constexpr int BVH_LEAF_MAX = 4;        // triangles per leaf (measured: 1 -> 2.74 ms, 2 -> 2.21 ms, 4 -> 2.12 ms per frame); fetched two at a time
