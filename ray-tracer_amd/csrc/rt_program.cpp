@@ -1015,6 +1015,7 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
     // lane handles by itself (a lone sphere / cube / cylinder, or a group that is nothing but one mesh) and the scene has no
     // CSG (the tree kernels with CSG code are the heaviest variants).  Measured, ranges / tree, ms per frame: 32 teapot
     // instances scattered at random, 960x540: 3.57 / 1.88 (64: 5.58 / 2.73); 32 spheres: 0.81 / 0.68 (96: 1.59 / 1.03); but a
+    // (16: 2.45 / 1.44; 16 spheres: 0.55 / 0.45; 12 spheres: 0.45 / 0.48); but a
     // regular grid of 16 teapots at 8K 13.1 / 14.3, of 36: 15.5 / 15.6; C5 at grid 4 (16 teapots + 16 two-triangle groups,
     // which the wavefront visits in turn) 14.1 / 15.3; C4 (9 objects, CSG and a hexagon among them) 5.4 / 8.3.
     size_t tlas_from = size_t(TLAS_MIN_OBJECTS);

@@ -145,7 +145,7 @@ constexpr int32_t TLAS_INSTANCE = 1 << 29;  // in a top-level leaf link ~c: c & 
                                             // instance, walked per lane) rather than of an object's ITEM_CULL (walked by the wavefront)
 constexpr int TLAS_MIN_OBJECTS = 64;     // fewer bounded top-level objects: nested ITEM_CULL ranges in program order (measured on C5
                                          // at 8K, ranges / tree: 32 objects 14.3 / 15.9 ms, 72: 17.1 / 17.0, 128: 19.0 / 18.0, 338: 24.8 / 20.5)
-constexpr int TLAS_MIN_INSTANCES = 32;   // ... but already from this many when every one of them is walked per lane (rt_program.cpp: compile_program)
+constexpr int TLAS_MIN_INSTANCES = 16;   // ... but already from this many when every one of them is walked per lane (rt_program.cpp: compile_program)
 constexpr int LBVH_MIN_TRIANGLES = 1024; // smaller meshes are always built on the host
 constexpr int MESH_MIN_TRIANGLES = 8;  // smaller triangle sets are tested one by one
 constexpr int BVH_LEAF_MAX = 4;        // triangles per leaf (measured: 1 -> 2.74 ms, 2 -> 2.21 ms, 4 -> 2.12 ms per frame); fetched two at a time
