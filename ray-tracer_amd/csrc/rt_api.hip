@@ -126,7 +126,7 @@ struct rt_scene {
     struct GraphEntry { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0;
-    std::string graph_last_key;  // the key of the last frame that was enqueued plainly (see render_shard_impl)
+    std::vector<std::string> graph_recent_keys;  // keys of the last few frames that were enqueued plainly (see render_shard_impl)
     bool use_graph = true;
     // rt_render_begin / rt_render_end: two device frames used in turn, the D2H copy of one on `copy_stream` while the
     // next is rendered on `stream`
@@ -810,8 +810,13 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
             if (g.key == key) { graph_exec = g.exec; g.used = ++s->graph_clock; }
         // A key is captured the SECOND time it is seen: a camera that moves every frame (an animation) never repeats one, and
         // capture + instantiation cost such a frame 5 % for nothing (1.67 against 1.59 ms on the headline scene)
-        const bool seen_before = graph_exec || key == s->graph_last_key;
-        if (!seen_before) s->graph_last_key = key;
+        // (the last few plainly enqueued keys are remembered, not just one: callers alternate between two output buffers)
+        bool seen_before = graph_exec != nullptr;
+        for (const std::string& k : s->graph_recent_keys) seen_before = seen_before || k == key;
+        if (!seen_before) {
+            if (s->graph_recent_keys.size() >= GRAPH_SLOTS) s->graph_recent_keys.erase(s->graph_recent_keys.begin());
+            s->graph_recent_keys.push_back(key);
+        }
         if (seen_before && !graph_exec) {
             if (s->graphs.size() >= GRAPH_SLOTS) {  // drop the least recently used one
                 size_t lru = 0;
