@@ -291,6 +291,10 @@ typedef struct rt_scene_opts {
     int32_t four_components;    /* -1/0: the library's rule — the 4-component path (see the note on w below) only for scenes
                                    and cameras that need it; 1: every call on this scene takes it, whatever its matrices
                                    (orders of magnitude slower: for checking that path against the other) [RT_AMD_GENERAL]    */
+    /* (struct_size >= 52) */
+    int32_t walk_bound;         /* the n1/n2 walk searches a mesh only as far back along the ray as a triangle there could still
+                                   be the last container at the hit (worked out from the entries of the other shapes, which
+                                   are listed first): -1/1 yes, 0 the whole line                       [RT_AMD_WALK_BOUND]    */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is

@@ -1084,7 +1084,7 @@ namespace {
 // rt_scene_opts with every -1 resolved: the field, else its RT_AMD_* variable, else the default
 struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
-    bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true, general = false;
+    bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true, general = false, walk_bound = true;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
 };
 void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
@@ -1106,6 +1106,7 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     k.fuse_spawn = pick(v.fuse_spawn, "RT_AMD_FUSE_SPAWN", true);
     k.tlas = pick(v.top_level_tree, "RT_AMD_TLAS", true);
     k.general = pick(v.four_components, "RT_AMD_GENERAL", false);
+    k.walk_bound = pick(v.walk_bound, "RT_AMD_WALK_BOUND", true);
     {   // 2: the tree, but every object left to the wavefront (no per-lane mesh instances)
         const char* e = std::getenv("RT_AMD_TLAS");
         k.tlas_instances = !(v.top_level_tree == 2 || (v.top_level_tree < 0 && e && std::atoi(e) == 2));
@@ -1285,6 +1286,22 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
             if (c >= 0 && uses[c] != 1) unique = false;
         }
         s->ds.passive_mesh_tris = unique && knobs.passive ? 1 : 0;
+        // ... and the walk may bound its mesh searches (WalkSink::before_mesh) when, besides, every mesh triangle has the same
+        // refractive index, bit for bit
+        s->ds.walk_bound_item = -1;
+        s->ds.walk_passive_ior = 1.;
+        if (s->ds.passive_mesh_tris && knobs.walk_bound && prog.walk_bound_item >= 0 && !prog.mesh_nodes.empty()) {
+            bool same = true;
+            uint64_t bits0 = 0;
+            for (size_t q = 0; q < prog.mesh_nodes.size() && same; ++q) {
+                const double ior = d.material_params[size_t(d.node_material[prog.mesh_nodes[q]]) * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+                uint64_t bits;
+                std::memcpy(&bits, &ior, 8);
+                if (q == 0) { bits0 = bits; s->ds.walk_passive_ior = ior; }
+                same = bits == bits0;
+            }
+            if (same) s->ds.walk_bound_item = prog.walk_bound_item;
+        }
     }
     if (knobs.verbose)
         std::fprintf(stderr, "rt_scene_create: %.3f s so far (compile + uploads)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create0).count());

@@ -87,6 +87,10 @@ struct DScene {
                                       //    itself (F14): the n1/n2 walk cannot be skipped at remaining == 0 (needs_walk)
     int32_t passive_mesh_tris;        // 1: every triangle of a mesh BVH is equal (Shape::eq) to no other node: WalkSink may drop
                                       //    all but the last of them below the hit (rt_kernels.hip.h)
+    int32_t walk_bound_item;          // >= 0: the program's first ITEM_MESH, with nothing but meshes behind it, in a scene whose mesh
+                                      //       triangles are passive and share one refractive index: WalkSink::before_mesh
+    int32_t _pad_walk;
+    double walk_passive_ior;          // ... that refractive index
     int32_t tlas_root;                // BVH4 over the bounded top-level objects (Program::tlas_root), -1: none
     int32_t n_linear;                 // items [0, n_linear) are walked by every ray; the rest only through the top-level tree
     double cull_reach;                // ITEM_CULL ranges are trusted for rays whose origin has max |coordinate| below this

@@ -836,8 +836,12 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // SC = scene class: bit 0 the scene has CSG nodes, bit 1 its program has ITEM_CULL ranges (code for either is only
 // compiled into the kernels of scenes that need it).
 constexpr int SC_CSG = 1, SC_CULL = 2, SC_BIG = 4, SC_TLAS = 8;  // SC_TLAS (with SC_CULL): the world has a top-level tree
+// `i_begin`, `i_end` (kernels without a top-level tree only; -1 = the program's end): walk that part of the program — the
+// n1/n2 walk visits the meshes in a call of their own (container_walk).  A part must not cut through a group, a cull range
+// or a CSG subtree (rt_program.cpp: walk_bound_item).
 template <int SC, bool COUNT, class Sink>
-__device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive) {
+__device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 ro, V3 rd, Sink& sink, Work& w, bool alive, int i_begin = 0,
+                                         int i_end = -1) {
     constexpr bool HAS_CSG = (SC & SC_CSG) != 0, HAS_CULL = (SC & SC_CULL) != 0, BIG = (SC & SC_BIG) != 0;
     constexpr bool HAS_TLAS = (SC & SC_TLAS) != 0 && HAS_CULL;
     CsgScratch<BIG>* cs = nullptr;
@@ -889,9 +893,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const TravMem& M, V3 r
     const RT_CONSTANT Item* __restrict__ items = as_constant(S.items);
     const RT_CONSTANT double* __restrict__ xf = as_constant(S.xf);
     const RT_CONSTANT int32_t* __restrict__ pool = as_constant(S.chain_pool);
-    const int n_items = S.n_items;
-    int until = alive ? 0 : n_items;
-    int i = 0;
+    const int n_items = !HAS_TLAS && i_end >= 0 ? i_end : S.n_items;
+    int i = HAS_TLAS ? 0 : i_begin;
+    int until = alive ? i : n_items;
     // Worlds with a top-level tree (SC_TLAS kernels): the first n_linear items are walked by every ray as ever; the bounded
     // objects behind them are ranges [ITEM_CULL, ..., skip) that a ray visits only when its own walk of the tree
     // (tlas_next) names them.  Each lane holds the next object ITS ray has to visit (`cand`).  While the lanes of the
@@ -1546,12 +1550,42 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
     WalkSink sink;
     sink.t = lt; sink.key = lk; sink.n = 0; sink.cap = list_cap; sink.limit = hit_t; sink.flags = 0;
     sink.below_t = -INFINITY; sink.below_key = -1; sink.hit_node = hit_node; sink.passive = S.passive_mesh_tris != 0;
-    traverse<SC, COUNT>(S, M, o, d, sink, w, alive);
-    sink.finish();
-    flags |= sink.flags;
-    const int n = sink.n < list_cap ? sink.n : list_cap;
     const int hit_cls = alive ? S.node_eq_class[hit_node] : -1;
     double n1 = 0., n2 = 0.;
+    // Round 3 — how far back the mesh search has to look.  A passive entry T (WalkSink) is only ever observed as
+    // containers.last() at an entry that equals the hit (`is_self` below: src/intersection.rs:56-62 before the toggle,
+    // :72-78 after it), and it is the last container there only if nothing pushed after it is still in the vector.  In a
+    // program whose meshes all come behind everything else (DScene::walk_bound_item: the mesh-free objects are emitted
+    // first, rt_program.cpp) the walk runs in two parts: the items in front of the first mesh, then the reference's loop
+    // over what they listed, then the meshes.  Passive entries can neither remove a container nor equal the hit, so the
+    // entries of the first part are toggled in that replay exactly as they will be in the full list, and every
+    // observation names the container on top, pushed at t_top: a passive entry below t_top is buried under it there.  An
+    // observation whose top has the refractive index that every mesh triangle of the scene has (walk_passive_ior; the
+    // empty vector reads as 1.0) reads the same value with or without a passive entry above it and asks for nothing.
+    // The minimum of t_top over the observations that do ask bounds the search (WalkSink::lo_mesh): a ray inside a glass
+    // sphere no longer searches a teapot that its line meets somewhere behind the sphere.  When the meshes add nothing to
+    // the list — nearly always — the first replay's n1 / n2 are the result.  No observation in the first part (the hit is
+    // a mesh triangle), a NaN in the list, a list that is not short: no bound, and the walk is what it was.
+    // rt_scene_opts.walk_bound = 0 switches it off (one part, bit-identical: tested).
+    const int split = S.walk_bound_item >= 0 && sink.passive ? S.walk_bound_item : S.n_items;
+    const long long passive_bits = __double_as_longlong(S.walk_passive_ior);
+    int n_replayed = -1;
+#pragma nounroll
+    for (int part = 0; part < 2; ++part) {
+    const int part_begin = part == 0 ? 0 : split, part_end = part == 0 ? split : S.n_items;
+    if (part_begin >= part_end && part == 1) break;
+    traverse<SC, COUNT>(S, M, o, d, sink, w, alive, part_begin, part_end);
+    const bool last_part = part == 1 || split >= S.n_items;
+    if (last_part) {
+        sink.finish();
+        flags |= sink.flags;
+    }
+    if (last_part && sink.n == n_replayed) break;  // (finish() included: the meshes added nothing)
+    n_replayed = sink.n;
+    const int n = sink.n < list_cap ? sink.n : list_cap;
+    n1 = 0.; n2 = 0.;
+    double bound = INFINITY;  // least push time of a container on top that a passive entry above it would change
+    bool observed = false;
     const bool is_short = n <= SHORT_LIST;
     if (is_short) {
         ShortList L;
@@ -1576,18 +1610,25 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
         }
         int ccls[SHORT_LIST];     // containers: equality class ...
         double cior[SHORT_LIST];  // ... and refractive index of each
+        float cpush[SHORT_LIST];  // ... and the t of the entry that pushed it, rounded DOWN to f32 (it only ever bounds a search from below)
 #pragma unroll
-        for (int k = 0; k < SHORT_LIST; ++k) { ccls[k] = -1; cior[k] = 1.; }
+        for (int k = 0; k < SHORT_LIST; ++k) { ccls[k] = -1; cior[k] = 1.; cpush[k] = -INFINITY; }
         int nc = 0;
 #pragma unroll
         for (int i = 0; i < SHORT_LIST; ++i) {
             if (i < n) {
+                if (!(L.t[i] == L.t[i])) bound = -INFINITY;  // a NaN in the list: no bound
                 const bool is_self = near_eq(L.t[i], hit_t) && cls[i] >= 0 && cls[i] == hit_cls;  // Intersection::eq (F6, F14)
                 double last = 1.;  // containers.last()'s refractive index, 1.0 when empty (src/intersection.rs:57-62)
+                float last_push = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < SHORT_LIST; ++k)
-                    if (k == nc - 1) last = cior[k];
-                if (is_self) n1 = last;
+                    if (k == nc - 1) { last = cior[k]; last_push = cpush[k]; }
+                if (is_self) {
+                    n1 = last;
+                    observed = true;
+                    if (__double_as_longlong(last) != passive_bits) bound = fmin(bound, (double)last_push);
+                }
                 int found = -1;  // position() of the first equal container (src/intersection.rs:65)
 #pragma unroll
                 for (int k = SHORT_LIST - 1; k >= 0; --k)
@@ -1595,24 +1636,27 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
                 if (found >= 0) {
 #pragma unroll
                     for (int k = 0; k + 1 < SHORT_LIST; ++k)
-                        if (k >= found) { ccls[k] = ccls[k + 1]; cior[k] = cior[k + 1]; }
+                        if (k >= found) { ccls[k] = ccls[k + 1]; cior[k] = cior[k + 1]; cpush[k] = cpush[k + 1]; }
                     --nc;
                 } else {
 #pragma unroll
                     for (int k = 0; k < SHORT_LIST; ++k)
-                        if (k == nc) { ccls[k] = cls[i]; cior[k] = ior[i]; }
+                        if (k == nc) { ccls[k] = cls[i]; cior[k] = ior[i]; cpush[k] = __double2float_rd(L.t[i]); }
                     ++nc;
                 }
                 if (is_self) {
                     double last2 = 1.;
+                    float last2_push = -INFINITY;
 #pragma unroll
                     for (int k = 0; k < SHORT_LIST; ++k)
-                        if (k == nc - 1) last2 = cior[k];
+                        if (k == nc - 1) { last2 = cior[k]; last2_push = cpush[k]; }
                     n2 = last2;
+                    if (__double_as_longlong(last2) != passive_bits) bound = fmin(bound, (double)last2_push);
                 }
             }
         }
     } else {
+        bound = -INFINITY;
         sort_list(lt, lk, n);
         int containers_private[BIG ? 1 : CONTAINER_CAP];
         int* containers = BIG ? lk + list_cap : containers_private;
@@ -1639,6 +1683,9 @@ __device__ __forceinline__ void container_walk(const DScene& S, const TravMem& M
             if (is_self) n2 = nc == 0 ? 1. : S.mat[(size_t)S.node_material[containers[nc - 1]] * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
         }
     }
+    // (entries inside the window of the hit, t > hit_t - 2 EPS, are listed in full whatever the bound)
+    if (!last_part && observed && hit_t == hit_t) sink.below_t = fmin(bound, hit_t - 2. * EPS);
+    }  // part
     n1_out = n1;
     n2_out = n2;
 }

@@ -1057,6 +1057,19 @@ int compile_program(const rt_scene_desc& d, Program& out, std::string& err, cons
     if (opts.cull_ranges && opts.top_level_tree && bounded.size() >= tlas_from) c.emit_tlas(bounded);
     else c.emit_culled(bounded, 0, bounded.size());
     if (out.tlas_root < 0) out.n_linear = int32_t(out.items.size());
+    if (out.tlas_root < 0) {  // the n1/n2 walk may bound its mesh searches once every non-mesh leaf has been listed
+        int32_t first = -1;
+        bool only_meshes_behind = true;
+        for (size_t i = 0; i < out.items.size(); ++i) {
+            if (out.items[i].type == ITEM_MESH) { if (first < 0) first = int32_t(i); }
+            else if (first >= 0) only_meshes_behind = false;
+        }
+        // (the walk is cut in two there: no group gate or cull range may reach across the cut)
+        for (int32_t i = 0; i < first && only_meshes_behind; ++i)
+            if ((out.items[size_t(i)].type == ITEM_GATE || out.items[size_t(i)].type == ITEM_CULL) && out.items[size_t(i)].skip > first)
+                only_meshes_behind = false;
+        out.walk_bound_item = only_meshes_behind ? first : -1;
+    }
     for (int32_t n = 0; n < d.n_nodes; ++n) {
         int32_t k = d.node_kind[n];
         if (k <= RT_SMOOTH_TRIANGLE) {

@@ -102,6 +102,8 @@ struct Program {
     double far_a = 0., far_b = 0., far_extent = 0.;
     double cull_min_dir2 = 0.;         // ... and whose direction is at least this long, squared (0.25 once a cube is bounded: its
                                        // padding covers the reference's leak only up to a parameter |t| of CUBE_PAD / EPSILON)
+    int32_t walk_bound_item = -1;      // index of the first ITEM_MESH when nothing but ITEM_MESH follows it and there is no top-level
+                                       // tree (every other leaf is listed by then: WalkSink::before_mesh), else -1
     bool has_smooth = false;
     bool all_cast_shadow = true;
     int32_t max_chain = 0;

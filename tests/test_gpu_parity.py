@@ -658,6 +658,69 @@ def test_passive_mesh_triangles_in_the_n1_n2_walk_change_nothing(monkeypatch):
         assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
 
 
+def _walk_bound_world(variant):
+    """Glass spheres (one nested in another) next to a teapot whose triangles lie on the lines of the rays inside them: what
+    the bound on the n1/n2 walk's mesh search (WalkSink::before_mesh) reasons about.  `variant` sets the refractive index of
+    the mesh triangles: "one" = 1.0 (what an empty `containers` reads as), "glass" = the index of the big sphere (the
+    container on top reads the same with or without a triangle above it), "other" = an index of its own (every
+    observation asks for the triangle), "two" = two meshes with different indices (the library must decline the bound),
+    "see-through" = a transparent teapot (hits on the mesh itself are walked)."""
+    w = World()
+    w.lights.append(Light.point_light((-6., 9., -8.), rt.WHITE))
+    w.objects.append(Shape.plane().set_transform(translate(0., -0.4, 0.)).set_material(Material(reflective=0.2, pattern=Pattern.checkered(rt.WHITE, rt.BLACK))))
+    ior = {"one": 1.0, "glass": 1.5, "other": 2.25, "two": 1.7, "see-through": 1.33}[variant]
+    teapot, _ = rt.obj_to_group(scenes.read_asset("teapot.obj"))
+    teapot.set_transform(translate(0.2, 0., 1.2) * scale(0.5, 0.5, 0.5)).set_material(
+        Material(color=(0.9, 0.6, 0.3), diffuse=0.6, reflective=0.2, refractive_index=ior,
+                 transparency=0.8 if variant == "see-through" else 0.))
+    w.objects.append(teapot)
+    if variant == "two":
+        low, _ = rt.obj_to_group(scenes.read_asset("teapot-low.obj"))
+        low.set_transform(translate(-3.2, 0., 2.5) * scale(0.35, 0.35, 0.35)).set_material(Material(color=(0.3, 0.6, 0.9), refractive_index=1.2))
+        w.objects.append(low)
+    glass = lambda n: Material(color=(1., 1., 1.), diffuse=0.1, ambient=0.05, reflective=0.5, transparency=0.9, refractive_index=n)
+    w.objects.append(Shape.glass_sphere().set_transform(translate(-1.6, 1.0, -1.6) * scale(1.3, 1.3, 1.3)).set_material(glass(1.5)))
+    w.objects.append(Shape.glass_sphere().set_transform(translate(-1.6, 1.0, -1.6) * scale(0.6, 0.6, 0.6)).set_material(glass(1.0)))   # air bubble
+    w.objects.append(Shape.glass_sphere().set_transform(translate(2.3, 0.8, -1.0) * scale(1.0, 1.0, 1.0)).set_material(glass(1.9)))
+    w.objects.append(Shape.cube().set_transform(translate(0.3, 0.3, -2.6) * scale(0.6, 0.6, 0.6)).set_material(glass(1.5)))
+    cam = Camera(80, 45, PI / 3)
+    cam.transform = view_transform((0.5, 2.6, -7.5), (0.1, 0.8, 0.), (0., 1., 0.))
+    return w, cam
+
+
+@pytest.mark.parametrize("variant", ["one", "glass", "other", "two", "see-through"])
+def test_walk_bound_changes_nothing(monkeypatch, variant):
+    """Round 3: the n1/n2 walk bounds its mesh search by what the entries of the other shapes leave observable
+    (rt_scene_opts.walk_bound).  Frames and rays that start INSIDE the glass bodies — their lines run back through the
+    teapot — against the oracle, and bit-identical with the bound switched off."""
+    w, cam = _walk_bound_world(variant)
+    g, o = assert_image_parity(w, cam)
+    assert g.stats.rays_container > 300 and g.stats.rays_refract > 300
+    rng = np.random.default_rng(len(variant))
+    centres = np.array([(-1.6, 1.0, -1.6), (-1.6, 1.0, -1.6), (2.3, 0.8, -1.0), (0.3, 0.3, -2.6)])
+    radii = np.array([1.25, 0.55, 0.95, 0.55])
+    n = 1600
+    pick = rng.integers(0, 4, size=n)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    ro = centres[pick] + u * (radii[pick] * rng.uniform(0., 1., size=n))[:, None]
+    # half of them aimed away from the teapot, so that it lies BEHIND the origin on the ray's line
+    away = ro - np.array([0.2, 0.6, 1.2]) + rng.normal(size=(n, 3)) * 0.4
+    rd = np.where((np.arange(n) % 2 == 0)[:, None], away, rng.normal(size=(n, 3)))
+    rd /= np.linalg.norm(rd, axis=1)[:, None]
+    g_rgb, g_id, g_fl = w.color_at_batch(ro, rd, 4)
+    o_rgb, o_id, o_fl = ob.color_at_batch(w, ro, rd, 4)
+    assert np.array_equal(g_id, o_id) and np.array_equal(g_fl, o_fl) and float(np.nanmax(np.abs(g_rgb - o_rgb))) < COLOR_TOL
+    monkeypatch.setenv("RT_AMD_WALK_BOUND", "0")
+    w0, cam0 = _walk_bound_world(variant)
+    plain = cam0.render(w0)
+    p_rgb, p_id, p_fl = w0.color_at_batch(ro, rd, 4)
+    monkeypatch.delenv("RT_AMD_WALK_BOUND")
+    assert np.array_equal(plain.rgb, g.rgb, equal_nan=True) and np.array_equal(plain.flags, g.flags)
+    assert plain.stats.total_rays == g.stats.total_rays and plain.stats.rays_container == g.stats.rays_container
+    # (object ids are drawn from a global counter: the second world's differ by a constant)
+    assert np.array_equal(p_rgb, g_rgb, equal_nan=True) and np.array_equal(p_id == 0, g_id == 0) and np.array_equal(p_fl, g_fl)
+
+
 def test_cull_ranges_are_not_trusted_from_very_far_away():
     """from ~1e5 radii away the reference's quadratic (c = o.o - 1, b^2 - 4ac) reports tangent hits a few 1e-7
     outside the unit sphere, further than the padding of the world-space cull boxes.  Rays aimed at the silhouette
@@ -1294,7 +1357,7 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
         w, cam = build(*size)
         ref = cam.render(w, depth=depth)
         for kw in ({"cull_ranges": 0}, {"passive_triangles": 0}, {"frame_graph": 0}, {"device_bvh": 1}, {"gather": 1},
-                   {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0}, {"top_level_tree": 0},
+                   {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0}, {"top_level_tree": 0}, {"walk_bound": 0},
                    {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0, "share_meshes": 0,
                     "fuse_output": 0, "fuse_spawn": 0}):
             ms = rt.MultiScene(w, [0], **kw)
