@@ -758,9 +758,11 @@ struct Compiler {
         tlas_header.assign(roots.size(), -1);
         for (size_t i = 0; i < roots.size(); ++i) {
             const size_t before = p.items.size();
+            tiny_mesh_root = RT_TLAS_PER_LANE && opts.tlas_instances ? roots[i].first : -1;
             emit_culled(roots, i, i + 1, true);   // ITEM_CULL(own box) + the object + skip
             tlas_header[i] = int32_t(before);
         }
+        tiny_mesh_root = -1;
         n2.clear();
         Box rb;
         const int32_t root2 = tlas_build(roots, 0, roots.size(), rb);
@@ -775,6 +777,29 @@ struct Compiler {
         it.chain_len = int32_t(chain.size());
         it.x0 = chain.size() > 0 ? chain[0] : 0;
         it.x1 = chain.size() > 1 ? chain[1] : 0;
+    }
+
+    // Under a top-level tree (emit_tlas) a bounded object that is nothing but triangles — under one group or under several
+    // nested ones that change nothing (no transform of their own, no gate: triangle groups have infinite boxes, F4), however
+    // few: triangles.obj is two groups of one triangle each — becomes ONE ITEM_MESH, so that its tree leaf is an instance and
+    // every lane meets the one ITS ray reached, instead of the wavefront visiting such objects one after the other.  (Keys are
+    // node * 4 + push whoever tests the triangle, and normals use the per-leaf registry chains: results cannot change.)
+    int32_t tiny_mesh_root = -1;  // the top-level object being emitted under emit_tlas (the rule applies to the object itself)
+    bool only_plain_triangles(int32_t group, std::vector<int32_t>& tris) const {
+        for (int32_t c = group + 1; c < d.node_subtree_end[group]; c = d.node_subtree_end[c]) {
+            if (d.node_xform[c] != 0) return false;
+            if (is_tri_kind(d.node_kind[c])) { tris.push_back(c); continue; }
+            if (d.node_kind[c] != RT_GROUP) return false;
+            const double* box = d.group_box + size_t(d.node_param[c]) * 6;
+            bool infinite = true, empty = true;
+            for (int k = 0; k < 3; ++k) {
+                infinite = infinite && box[k] == -INF && box[3 + k] == INF;
+                empty = empty && box[k] == INF && box[3 + k] == -INF;
+            }
+            if (!infinite && !empty) return false;
+            if (!only_plain_triangles(c, tris)) return false;
+        }
+        return true;
     }
 
     void emit(int32_t node, std::vector<int32_t> chain) {
@@ -816,6 +841,20 @@ struct Compiler {
                 p.items.push_back(it);
             }
             std::vector<int32_t> tris;
+            if (node == tiny_mesh_root && gate < 0 && only_plain_triangles(node, tris) && !tris.empty()) {
+                Item it{};
+                it.type = ITEM_MESH;
+                it.node = node;
+                set_chain(it, chain);
+                it.a = build_mesh(tris, node);
+                it.b = int32_t(p.mesh_box.size() / 6);
+                for (int k = 0; k < 3; ++k) p.mesh_box.push_back(last_mesh_box.lo[k]);
+                for (int k = 0; k < 3; ++k) p.mesh_box.push_back(last_mesh_box.hi[k]);
+                mesh_items.push_back(p.items.size());
+                p.items.push_back(it);
+                return;
+            }
+            tris.clear();
             for (int32_t c = node + 1; c < d.node_subtree_end[node]; c = d.node_subtree_end[c])
                 if (is_tri_kind(d.node_kind[c]) && d.node_xform[c] == 0) tris.push_back(c);
             bool mesh = tris.size() >= size_t(MESH_MIN_TRIANGLES);

@@ -247,10 +247,12 @@ def many_objects_scene(seed=0, hsize=96, vsize=54, n=40):
     return w, cam
 
 
-def instanced_small_meshes(seed=0, hsize=96, vsize=54, n=80, smooth=False):
+def instanced_small_meshes(seed=0, hsize=96, vsize=54, n=80, smooth=False, tiny=0):
     """n separately parsed copies of one small OBJ mesh (a 4 x 4 height field: 32 triangles, optionally with vertex
     normals) scattered with their own rotations and scales over a mirror floor, a few of them glass: a world of mesh
-    INSTANCES small enough for the brute-force oracle.  Every copy is an object of its own (one ITEM_MESH)."""
+    INSTANCES small enough for the brute-force oracle.  Every copy is an object of its own (one ITEM_MESH).  `tiny`: as many
+    copies of triangles.obj on top — two named groups of ONE triangle each under the object's group, which the program
+    compiler turns into one two-triangle mesh under a top-level tree (rt_program.cpp: only_plain_triangles)."""
     rng = np.random.RandomState(5100 + seed)
     hgt = rng.uniform(-0.3, 0.5, size=(5, 5))
     lines = []
@@ -281,6 +283,14 @@ def instanced_small_meshes(seed=0, hsize=96, vsize=54, n=80, smooth=False):
             g.set_material(Material(color=(1., 1., 1.), diffuse=0.2, reflective=0.4, transparency=0.7, refractive_index=1.3))
         else:
             g.set_material(Material(color=tuple(rng.uniform(0.2, 1., 3)), diffuse=0.7, specular=0.4, reflective=0.25 if k % 3 == 0 else 0.))
+        w.objects.append(g)
+    for k in range(tiny):
+        g, _ = rt.obj_to_group(read_asset("triangles.obj"))
+        size = float(rng.uniform(0.8, 2.))
+        g.set_transform(translate(rng.uniform(-10., 10.), rng.uniform(0.2, 3.5), rng.uniform(-2., 20.)) * rotate(rng.uniform(0., 2. * PI), Axis.Y) *
+                        rotate(rng.uniform(-1.2, 1.2), Axis.X) * scale(size, size, size))
+        g.set_material(Material(color=(0.9, 0.9, 0.3), reflective=0.3) if k % 3 else
+                       Material(color=(1., 1., 1.), diffuse=0.2, reflective=0.3, transparency=0.8, refractive_index=1.4))
         w.objects.append(g)
     cam = Camera(hsize, vsize, PI / 3.)
     cam.transform = view_transform((0., 8., -15.), (0., 1., 8.), (0., 1., 0.))

@@ -603,8 +603,8 @@ def test_top_level_tree_changes_nothing(monkeypatch):
     for env in (None, "2"):    # mesh instances walked per lane / every object left to the wavefront: the oracle's frame either way
         if env:
             monkeypatch.setenv("RT_AMD_TLAS", env)
-        for smooth in (False, True):
-            w, cam = scenes.instanced_small_meshes(3 + int(smooth), 96, 54, n=80, smooth=smooth)
+        for smooth, tiny in ((False, 0), (True, 0), (False, 30)):   # tiny: triangles.obj copies, one two-triangle mesh each
+            w, cam = scenes.instanced_small_meshes(3 + int(smooth), 96, 54, n=80 - tiny, smooth=smooth, tiny=tiny)
             assert_image_parity(w, cam, 6)
             o, d = _random_rays(3000, 77, center=(0., 1.5, 9.), radius=22.)
             gc, gt, gi = w.intersect_world_batch(o, d, 64)
