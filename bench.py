@@ -110,7 +110,7 @@ def measure_traffic(args):
         import pmc_traffic
     except Exception:
         return None
-    child = ["python3", os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--traffic", "file",
+    child = ["python3", os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c5", "--traffic", "file", "--in-flight", "1",
              "--scene", args.scene, "--grid", str(args.grid), "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
     tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -154,6 +154,10 @@ def main():
     ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_smooth", "teapot_low", "mixed", "book", "grid"])
     ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="N = 1: frames in flight in the timed region.  2 (default): rt_render_frame_begin / rt_render_end, the frames "
+                         "rendered side by side on two streams (a frame's launch tails are filled by the other frame's launches); "
+                         "1: one blocking rt_render_frame per frame (what the profile scripts trace: launches not overlapped)")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="N = 1 only: take the N > 1 code path (rt_render_shard, RCCL gather in a one-rank group, rt_assemble_strided)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 workloads (grid 4 and grid 13 at 8K) reported beside the headline")
@@ -217,6 +221,7 @@ def main():
         shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if sharded else 0)]
         gather_done = [None, None]
         frame = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+        frame_b = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if not sharded else None  # second frame in flight
         # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
         gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and sharded) else None
         gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
@@ -282,7 +287,21 @@ def main():
                 phases["assemble_ms"] = phases.get("assemble_ms", 0.) + e[1].elapsed_time(ev)
                 phases["frames"] = phases.get("frames", 0) + 1
 
-        return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, gathered_all), "frame": frame}
+        def frames_in_flight(n):
+            """n frames, two in flight (one GPU): frame k is handed to rt_render_frame_begin as soon as frame k - 2 has been
+            retired; every one of the n frames is complete in its device frame when this returns"""
+            bufs = (frame.data_ptr(), frame_b.data_ptr())
+            for k in range(n):
+                if k >= 2 and rt.lib.rt_render_end(scene) < 0:
+                    raise RuntimeError(rt.last_error())
+                if rt.lib.rt_render_frame_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1], None, None) < 0:
+                    raise RuntimeError(rt.last_error())
+            for _ in range(min(n, 2)):
+                if rt.lib.rt_render_end(scene) < 0:
+                    raise RuntimeError(rt.last_error())
+
+        return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, frame_b, gathered_all), "frame": frame,
+                "frames_in_flight": None if sharded else frames_in_flight}
 
     def sharded_report(step, frames=5):
         """Per-rank phase times of the sharded path, a few untimed frames each waited for: what the first real N > 1 run needs
@@ -303,14 +322,21 @@ def main():
                         "shard is in HBM), gather_ms / assemble_ms = events on the stream the gather and the scatter are enqueued on "
                         "(assemble runs on rank 0 only)" % frames}
 
-    def timed(step, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks, in ms per step."""
-        for _ in range(warmup):
-            step()
+    def timed(step, steps, warmup, many=None):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks, in ms per step.
+        `many(n)`: n steps in one call (two frames in flight) instead of n calls of step()."""
+        if many:
+            many(warmup)
+        else:
+            for _ in range(warmup):
+                step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if many:
+            many(steps)
+        else:
+            for _ in range(steps):
+                step()
         barrier()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if sharded:
@@ -334,7 +360,10 @@ def main():
     w, cam = builders[args.scene](args.width, args.height)
     job = make_job(w, cam, args.depth, args.width, args.height)
     step, scene, cd, opts = job["step"], job["scene"], job["cd"], job["opts"]
-    ms_per_step = timed(step, args.steps, args.warmup)
+    piped = args.in_flight == 2 and not sharded
+    ms_per_step = timed(step, args.steps, args.warmup, job["frames_in_flight"] if piped else None)
+    # one frame at a time (the latency of a frame; what `value` was until round 3's last step), beside the pipelined rate
+    ms_single = timed(step, min(args.steps, 100), 3) if piped else ms_per_step
 
     # ---- SURVEY 8(d)'s literal metric, reported next to `value`: rt_render = the same frame with HOST output buffers
     # (one 49.8 MB D2H copy of the f64 frame at 1080p included).  Never `value`: that is the HBM-resident rate.
@@ -356,17 +385,18 @@ def main():
         def time_rt_render_pipelined():
             """rt_render_begin / rt_render_end: the same frames into two page-locked host buffers used in turn, the D2H copy of
             frame k on a copy stream while frame k + 1 is rendered; every frame is complete in host memory when its end returns"""
-            bufs = [rt.pinned_array((args.height, args.width, 3)) for _ in range(2)]
-            def run(n):
+            bufs = [rt.pinned_array((args.height, args.width, 3)) for _ in range(4)]
+            def run(n):   # four in flight: two being rendered (side by side), two being copied
                 for k in range(n):
-                    rc = rt.lib.rt_render_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1].ctypes.data_as(rt.c_dp), None, None)
+                    if k >= 4 and rt.lib.rt_render_end(scene) < 0:
+                        raise RuntimeError(rt.last_error())
+                    rc = rt.lib.rt_render_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 3].ctypes.data_as(rt.c_dp), None, None)
                     if rc < 0:
                         raise RuntimeError(rt.last_error())
-                    if k >= 1 and rt.lib.rt_render_end(scene) < 0:
+                for _ in range(min(n, 4)):
+                    if rt.lib.rt_render_end(scene) < 0:
                         raise RuntimeError(rt.last_error())
-                if rt.lib.rt_render_end(scene) < 0:
-                    raise RuntimeError(rt.last_error())
-            run(4)
+            run(8)
             n_host = max(6, min(args.steps, 40))
             t0 = time.perf_counter()
             run(n_host)
@@ -400,10 +430,12 @@ def main():
         def run_c5(grid, what):
             w5, cam5 = scenes.instanced_grid(7680, 4320, grid=grid)
             job5 = make_job(w5, cam5, 8, 7680, 4320)
-            ms5 = timed(job5["step"], 20, 3)
+            ms5 = timed(job5["step"], 20, 4, job5["frames_in_flight"] if piped else None)
+            ms5_single = timed(job5["step"], 10, 2) if piped else ms5
             _, rays5 = ray_counts(job5["step"])
             out5 = {"workload": what, "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-                    "steps": 20, "warmup": 3, "rays_per_frame": sum(rays5[:4]), "n_gpus": world,
+                    "steps": 20, "warmup": 4, "rays_per_frame": sum(rays5[:4]), "n_gpus": world, "frames_in_flight": 2 if piped else 1,
+                    "one_frame_at_a_time": {"ms_per_frame": round(ms5_single, 4), "Mrays_s": round(sum(rays5[:4]) / (ms5_single * 1e-3) / 1e6, 3)},
                     "sharded": sharded_report(job5["step"], 3)}
             w5.invalidate()
             del job5
@@ -528,16 +560,24 @@ def main():
                           "parallelism": "tile-shard x%d, RCCL gather" % world if sharded else "single GPU"},
                "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
                                   "total": total_rays, "shaded_nodes": rays[4]},
-               "value_is": "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), scene resident before the "
-                           "timed region",
+               "value_is": ("rt_render_frame_begin / rt_render_end: Camera::render frame after frame with the Canvas left in HBM "
+                            "(row-major f64), TWO frames in flight — rendered side by side on two streams, a frame's launch tails "
+                            "filled by the other frame's launches; all K frames are complete inside the timed region; scene resident "
+                            "before it.  `one_frame_at_a_time` is the same frame with one blocking rt_render_frame per frame (a "
+                            "frame's latency, and what `value` was up to round 3's r03b set); the roofline object is quoted on "
+                            "launches of such frames" if piped else
+                            "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), one blocking call per frame, "
+                            "scene resident before the timed region"),
+               "frames_in_flight": 2 if piped else 1,
+               "one_frame_at_a_time": {"ms_per_frame": round(ms_single, 4), "Mrays_s": round(total_rays / (ms_single * 1e-3) / 1e6, 3)},
                "rt_render_host": None if host_ms is None else {
                    "ms_per_frame": round(host_ms_pipelined, 4), "Mrays_s": round(total_rays / (host_ms_pipelined * 1e-3) / 1e6, 3),
                    "ms_per_frame_blocking_rt_render": round(host_ms, 4),
                    "ms_per_frame_pageable_buffer": round(host_ms_pageable, 4),
                    "what": "SURVEY 8(d)'s wording of the metric — every frame complete in a HOST f64 buffer, the D2H copy of %.1f MB "
                            "included; PCIe-inclusive, so never `value`.  ms_per_frame: rt_render_begin / rt_render_end, frame "
-                           "after frame into two page-locked buffers (rt_host_alloc) used in turn, the copy of frame k on a copy "
-                           "stream beside the render of frame k + 1; ms_per_frame_blocking_rt_render: one rt_render call per frame "
+                           "after frame into four page-locked buffers (rt_host_alloc) used in turn, four frames in flight: two being "
+                           "rendered side by side, two being copied on a copy stream; ms_per_frame_blocking_rt_render: one rt_render call per frame "
                            "(render, then copy) into a page-locked buffer; the last figure: rt_render into pageable memory"
                            % (args.height * args.width * 24 / 1e6)},
                "sharded": sharded_info,

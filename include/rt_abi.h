@@ -322,17 +322,30 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
               int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats_out);
 
 /* Camera::render (src/camera.rs:62-74, which RETURNS a host Canvas) for callers that render frame after frame: the
- * same frame as rt_render into the same HOST buffers, but the device-to-host copy is taken off the critical path.
- * rt_render_begin renders the frame (whole frames only: opts->rank 0 of 1, opts->stream ignored) into one of two
- * device frames the scene uses in turn, enqueues the copies to rgb_out / hit_id_out / flags_out (the last two nullable)
- * on a copy stream of its own and returns; the buffers hold the frame once the matching rt_render_end has returned.
- * At most two frames may be in flight; rt_render_end retires the oldest one (and returns RT_OK at once when none is).
- *     begin(A); begin(B); end() -> A complete; begin(A'); end() -> B complete; ...
- * so the 0.85 ms copy of a 1920x1080 f64 frame overlaps the next frame's render: 1.7 instead of 2.5 ms per frame at the
- * host (buffers from rt_host_alloc; a pageable buffer makes the runtime stage the copy and the overlap is lost).  The
- * caller must not touch a buffer between its begin and the end that retires it.  rt_scene_destroy retires everything. */
+ * same frame as rt_render into the same HOST buffers, with two frames in flight.  rt_render_begin hands the frame (whole
+ * frames only: opts->rank 0 of 1, opts->stream ignored) to one of two render slots and returns; a slot renders into a
+ * device frame of its own on a stream of its own and copies to rgb_out / hit_id_out / flags_out (the last two nullable) on a
+ * copy stream; the buffers hold the frame once the matching rt_render_end has returned.  At most FOUR frames may be in
+ * flight (two being rendered — frames are dealt to the two render slots in turn, and a begin waits for the render of the
+ * frame two before it — and two being copied); rt_render_end retires the oldest one (and returns RT_OK at once when none
+ * is) and returns ITS result: an error of a frame's render surfaces there, not at its begin (rt_last_error has the text).
+ *     begin(A); begin(B); begin(C); end() -> A complete; begin(D); end() -> B complete; begin(A'); ...
+ * Round 2 overlapped the 0.85 ms copy of a 1920x1080 f64 frame with the next frame's render (2.5 -> 1.63 ms per frame at the
+ * host); round 3 also renders the two frames side by side — each traversal launch ends in a tail of a few long rays during
+ * which most of the chip is idle, and a launch of the OTHER frame's stream fills it — so a sequence of
+ * frames comes out at 1.1-1.2 ms per frame where one frame alone takes 1.5.  The second slot is a shallow copy of the scene
+ * made on first use: it shares the scene's read-only tables and owns its queues (about as much device memory again as the
+ * scene's queues take).  Buffers from rt_host_alloc keep the copy off the critical path (a pageable buffer makes the
+ * runtime stage it).  The caller must not touch a buffer between its begin and the end that retires it; any other call on
+ * the scene first waits for the renders in flight.  rt_scene_destroy retires everything.
+ *
+ * rt_render_frame_begin is the same with the Canvas left in DEVICE memory (rt_render_frame's arguments; frames in flight
+ * must be different buffers; two in flight are all it can use); it shares the slots, and rt_render_end retires its frames
+ * too. */
 int rt_render_begin(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
                     int32_t* hit_id_out, uint8_t* flags_out);
+int rt_render_frame_begin(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_frame,
+                          int32_t* d_hit_id_frame, uint8_t* d_flags_frame);
 int rt_render_end(rt_scene* scene);
 
 /* Number of pixels shard `rank` of `n_ranks` renders (8x8-pixel tiles of the (hsize-1)x(vsize-1) domain dealt

@@ -131,9 +131,33 @@ struct rt_scene {
     // rt_render_begin / rt_render_end: two device frames used in turn, the D2H copy of one on `copy_stream` while the
     // next is rendered on `stream`
     hipStream_t copy_stream = nullptr;
-    GrowBuf pipe_rgb[2], pipe_id[2], pipe_flags[2];
-    hipEvent_t pipe_rendered[2] = {nullptr, nullptr}, pipe_copied[2] = {nullptr, nullptr};
-    int pipe_head = 0, pipe_pending = 0;
+    static constexpr int PIPE_SLOTS = 4;  // frames in flight at most: two being rendered (slot & 1 = the render lane), two being copied
+    GrowBuf pipe_rgb[PIPE_SLOTS], pipe_id[PIPE_SLOTS], pipe_flags[PIPE_SLOTS];
+    hipEvent_t pipe_rendered[PIPE_SLOTS] = {}, pipe_copied[PIPE_SLOTS] = {};
+    int pipe_head = 0, pipe_pending = 0;  // next slot to use; frames begun and not yet retired (the most recent slots)
+    // Round 3: the two frames in flight are RENDERED side by side as well.  Every traversal launch ends in a tail of a few
+    // long rays, and a 1024-lane workgroup keeps its compute unit's LDS until its last wavefront is through, so a launch of
+    // the same stream cannot start there; a launch of ANOTHER stream's frame can take the compute units that are already
+    // free (measured: two frames at once 2.23 ms, one after the other 2.94).  Slot 0 renders on this scene, slot 1 on
+    // `twin`: a shallow copy that shares the read-only scene tables and owns everything a frame writes (stream, level
+    // queues, counters, stack spill area, arena, graphs); each slot has a host thread that runs the frame's (blocking)
+    // render and the copy, rt_render_end waits for the oldest.
+    // Both slots render on NON-BLOCKING streams (`pipe_stream` here, the twin's own): a slot's host thread may be capturing
+    // its frame graph while the caller's thread uses the legacy default stream (torch does), which is an error for a
+    // blocking stream under capture.  What a blocking stream gives implicitly — work the caller enqueued on the default
+    // stream before the call is done before the frame is written — is kept by an event recorded on the default stream at
+    // the begin (`pipe_ready`), which the slot's stream waits for.
+    rt_scene* twin = nullptr;
+    bool is_twin = false, twin_failed = false;
+    struct Worker* pipe_worker[2] = {nullptr, nullptr};
+    hipStream_t pipe_stream = nullptr;
+    hipEvent_t pipe_ready[PIPE_SLOTS] = {};
+    bool pipe_host[PIPE_SLOTS] = {};  // the slot's frame in flight goes to host buffers (rt_render_end waits for its copy)
+    // a lane's host thread runs one job at a time: before it is given the next frame, the result of the one it has just
+    // finished is put aside here for the rt_render_end that retires that frame
+    bool pipe_harvested[PIPE_SLOTS] = {};
+    int pipe_rc[PIPE_SLOTS] = {};
+    std::string pipe_err[PIPE_SLOTS];
     bool fuse_output = true;   // graph path: level 0's k_shade writes the shard / frame (RT_AMD_FUSE_OUTPUT=0: A/B)
     bool fuse_spawn = true;    // k_trace makes the rays of levels 1.. as it fetches them (RT_AMD_FUSE_SPAWN=0: k_spawn launches, A/B)
     bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
@@ -772,6 +796,11 @@ int general_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts*
     return RT_OK;
 }
 
+// Set by the host threads of rt_render_begin's two slots: their frames are enqueued launch by launch (with no host wait
+// between launches that is worth ~1 % of a frame), never captured — two threads capturing and instantiating graphs at the
+// same time while the caller's thread uses the default stream is more than the frames in flight need.
+thread_local bool t_plain_enqueue = false;
+
 // Camera::render for one shard, all work ordered on `st`, complete (the host has waited) when it returns.
 int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, hipStream_t st, double* d_rgb,
                       int32_t* d_id, uint8_t* d_flags, rt_stats* stats, CameraParams& c, long long& n_slots, bool frame = false) {
@@ -792,7 +821,7 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
     };
     // ---- the plain path (no statistics): the whole frame replayed as one HIP graph while nothing it bakes in changes
-    if (!stats && !opts->want_counters && s->use_graph && levels_sized(s, D)) {
+    if (!stats && !opts->want_counters && s->use_graph && !t_plain_enqueue && levels_sized(s, D)) {
         std::string key;
         auto put = [&key](const void* p, size_t n) { key.append(static_cast<const char*>(p), n); };
         // the camera by its named fields (`c` is derived from exactly those; the struct's padding bytes are not part of
@@ -907,10 +936,14 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     return RT_OK;
 }
 
-bool check_scene(rt_scene* s) {
+void wait_for_frames_in_flight(rt_scene* s);
+// `pipe_call`: rt_render_begin / rt_render_frame_begin / rt_render_end themselves.  Any other call on a scene with frames in
+// flight first waits for their renders (they use the scene's queues); the frames still have to be retired by rt_render_end.
+bool check_scene(rt_scene* s, bool pipe_call = false) {
     if (!s) { rt_set_error("null scene handle"); return false; }
     hipError_t e = hipSetDevice(s->device);
     if (e != hipSuccess) { rt_set_error("hipSetDevice(%d): %s", s->device, hipGetErrorString(e)); return false; }
+    if (!pipe_call && s->pipe_pending > 0) wait_for_frames_in_flight(s);
     return true;
 }
 
@@ -1035,6 +1068,60 @@ struct Worker {
         if (th.joinable()) th.join();
     }
 };
+
+namespace {
+void wait_for_frames_in_flight(rt_scene* s) {
+    for (int k = 0; k < 2; ++k)
+        if (s->pipe_worker[k]) (void)s->pipe_worker[k]->wait();
+}
+}  // namespace
+static void destroy_pipe_workers(rt_scene* s) {
+    for (int k = 0; k < 2; ++k) {
+        delete s->pipe_worker[k];
+        s->pipe_worker[k] = nullptr;
+    }
+}
+
+// The scene that renders the second frame in flight (rt_scene::twin): shares every read-only table of `s` by pointer — the
+// tables are never written after creation — and owns what a frame writes.  Nothing here is undone on failure except the
+// twin itself: the caller then renders both slots on `s`, one after the other, as before.
+static int make_twin(rt_scene* s) {
+    std::unique_ptr<rt_scene, void (*)(rt_scene*)> t(new rt_scene(), [](rt_scene* x) { rt_scene_destroy(x); });
+    t->is_twin = true;
+    t->device = s->device;
+    t->ds = s->ds;
+    t->ds.spill = nullptr;
+    t->ds.arena = nullptr;
+    t->ds.arena_lane_bytes = 0;
+    t->ds.arena_csg_cap = t->ds.arena_list_cap = 0;
+    t->gs = s->gs;          // the 4-component path's tables; its counters and slab are made on first use, per scene
+    t->gs.counters = nullptr;
+    t->gs.slab = nullptr;
+    t->has_csg = s->has_csg; t->has_smooth = s->has_smooth; t->any_transparent = s->any_transparent; t->has_tlas = s->has_tlas;
+    t->leaf_kind = s->leaf_kind;
+    t->meshes_built_on_gpu = s->meshes_built_on_gpu; t->meshes_shared = s->meshes_shared;
+    t->scene_class = s->scene_class;
+    t->n_lights = s->n_lights;
+    t->use_graph = s->use_graph; t->fuse_output = s->fuse_output; t->fuse_spawn = s->fuse_spawn; t->spawns = s->spawns;
+    t->trav_lds_bytes = s->trav_lds_bytes;
+    t->n_cus = s->n_cus;
+    t->general = s->general;
+    if (s->ds.spill) {  // the traversal stacks' spill rows are written by every traversal launch: one area per stream
+        size_t bytes = 0;
+        void* base = nullptr;
+        HIP_TRY(hipMemGetAddressRange(&base, &bytes, s->ds.spill));
+        void* sp = nullptr;
+        HIP_TRY(hipMalloc(&sp, bytes));
+        t->allocs.push_back(sp);
+        t->ds.spill = static_cast<int32_t*>(sp);
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    int rc = ensure_counters(t.get(), 16);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->h_word), sizeof(long long), hipHostMallocDefault));
+    s->twin = t.release();
+    return RT_OK;
+}
 
 struct MultiState {
     std::vector<rt_scene*> replicas;  // [0] is the scene that owns this state; the others are whole scenes of their own
@@ -1370,19 +1457,24 @@ void rt_scene_destroy(rt_scene* s) {
         delete ms;
     }
     (void)hipSetDevice(s->device);
+    destroy_pipe_workers(s);  // joins the threads: nothing of a frame in flight is left running
+    if (s->twin) { rt_scene_destroy(s->twin); s->twin = nullptr; }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : s->allocs) (void)hipFree(p);
     for (LevelStore& l : s->levels)
         if (l.block) (void)hipFree(l.block);
     for (rt_scene::GraphEntry& g : s->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < rt_scene::PIPE_SLOTS; ++k) {
         if (s->pipe_copied[k]) { (void)hipEventSynchronize(s->pipe_copied[k]); (void)hipEventDestroy(s->pipe_copied[k]); }
         if (s->pipe_rendered[k]) (void)hipEventDestroy(s->pipe_rendered[k]);
         for (GrowBuf* b : {&s->pipe_rgb[k], &s->pipe_id[k], &s->pipe_flags[k]})
             if (b->p) (void)hipFree(b->p);
     }
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
+    if (s->pipe_stream) { (void)hipStreamSynchronize(s->pipe_stream); (void)hipStreamDestroy(s->pipe_stream); }
+    for (int k = 0; k < rt_scene::PIPE_SLOTS; ++k)
+        if (s->pipe_ready[k]) (void)hipEventDestroy(s->pipe_ready[k]);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (LevelStore& l : s->fix_levels)
         if (l.block) (void)hipFree(l.block);
@@ -1561,55 +1653,119 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
     return RT_OK;
 }
 
-// Camera::render (src/camera.rs:62-74) with the copy of the Canvas to the host taken off the critical path: the frame is
-// rendered into one of two device frames used in turn, its D2H copy is enqueued on a stream of its own, and the call
-// returns; the copy of frame k then overlaps the render of frame k + 1.  See include/rt_abi.h.
-int rt_render_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
-                    uint8_t* flags_out) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+// Camera::render (src/camera.rs:62-74) frame after frame, two frames in flight: see include/rt_abi.h and rt_scene::twin.
+// `host`: the frame goes to HOST buffers (rendered into one of the scene's two device frames, copied on the copy stream);
+// otherwise it is left in the caller's DEVICE frame.
+static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, bool host, double* rgb_out, int32_t* hit_id_out,
+                      uint8_t* flags_out, const char* who) {
+    if (!check_scene(s, true)) return RT_ERR_BAD_ARG;
     if (!opts || !rgb_out || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
-    if (opts->n_ranks != 1 || opts->rank != 0) { rt_set_error("rt_render_begin renders whole frames (rank 0 of 1)"); return RT_ERR_BAD_ARG; }
+    if (opts->n_ranks != 1 || opts->rank != 0) { rt_set_error("%s renders whole frames (rank 0 of 1)", who); return RT_ERR_BAD_ARG; }
     if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
-    if (s->pipe_pending >= 2) { rt_set_error("two frames are in flight already: call rt_render_end first"); return RT_ERR_BAD_ARG; }
-    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    if (s->pipe_pending >= rt_scene::PIPE_SLOTS) { rt_set_error("%d frames are in flight already: call rt_render_end first", rt_scene::PIPE_SLOTS); return RT_ERR_BAD_ARG; }
     const int k = s->pipe_head;
-    if (!s->pipe_rendered[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_rendered[k], hipEventDisableTiming));
-    if (!s->pipe_copied[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_copied[k], hipEventDisableTiming));
     const size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
     int rc;
-    if ((rc = grow(s->pipe_rgb[k], npx * 3 * sizeof(double))) != RT_OK) return rc;
-    if (hit_id_out && (rc = grow(s->pipe_id[k], npx * sizeof(int32_t))) != RT_OK) return rc;
-    if (flags_out && (rc = grow(s->pipe_flags[k], npx)) != RT_OK) return rc;
-    double* d_rgb = static_cast<double*>(s->pipe_rgb[k].p);
-    int32_t* d_id = hit_id_out ? static_cast<int32_t*>(s->pipe_id[k].p) : nullptr;
-    uint8_t* d_fl = flags_out ? static_cast<uint8_t*>(s->pipe_flags[k].p) : nullptr;
-    hipStream_t st = s->stream;  // (a caller stream would have to be ordered against the copy stream by the caller)
-    // this device frame's previous copy was waited for by the rt_render_end that retired it (pipe_pending < 2)
-    if ((rc = clear_frame_border(st, cam, d_rgb, d_id, d_fl)) != RT_OK) return rc;
-    rt_render_opts o = *opts;
-    o.stream = nullptr;
-    CameraParams c;
-    long long n_slots = 0;
-    rc = render_shard_impl(s, cam, &o, st, d_rgb, d_id, d_fl, nullptr, c, n_slots, true);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipEventRecord(s->pipe_rendered[k], st));
-    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->pipe_rendered[k], 0));
-    HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-    if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, d_id, npx * sizeof(int32_t), hipMemcpyDeviceToHost, s->copy_stream));
-    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, d_fl, npx, hipMemcpyDeviceToHost, s->copy_stream));
-    HIP_TRY(hipEventRecord(s->pipe_copied[k], s->copy_stream));
-    s->pipe_head = k ^ 1;
+    double* d_rgb = rgb_out;
+    int32_t* d_id = hit_id_out;
+    uint8_t* d_fl = flags_out;
+    if (host) {
+        if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        if (!s->pipe_rendered[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_rendered[k], hipEventDisableTiming));
+        if (!s->pipe_copied[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_copied[k], hipEventDisableTiming));
+        // (this device frame's previous copy was waited for by the job that made it, before that slot was retired)
+        if ((rc = grow(s->pipe_rgb[k], npx * 3 * sizeof(double))) != RT_OK) return rc;
+        if (hit_id_out && (rc = grow(s->pipe_id[k], npx * sizeof(int32_t))) != RT_OK) return rc;
+        if (flags_out && (rc = grow(s->pipe_flags[k], npx)) != RT_OK) return rc;
+        d_rgb = static_cast<double*>(s->pipe_rgb[k].p);
+        d_id = hit_id_out ? static_cast<int32_t*>(s->pipe_id[k].p) : nullptr;
+        d_fl = flags_out ? static_cast<uint8_t*>(s->pipe_flags[k].p) : nullptr;
+    }
+    if (!s->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream, hipStreamNonBlocking));
+    if (!s->pipe_ready[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_ready[k], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->pipe_ready[k], nullptr));  // what the caller has enqueued on the default stream so far
+    if (!s->twin && !s->twin_failed && make_twin(s) != RT_OK) s->twin_failed = true;
+    // two render lanes, frames dealt to them in turn; without a twin there is one lane and the frames are rendered one after
+    // the other (their copies still overlap the renders)
+    const int lane = s->twin ? (k & 1) : 0;
+    rt_scene* rs = lane == 1 ? s->twin : s;
+    if (!s->pipe_worker[lane]) s->pipe_worker[lane] = new Worker();
+    Worker* w = s->pipe_worker[lane];
+    {   // the lane's previous frame, if it is still to be retired: wait for its render and put its result aside
+        const int step = s->twin ? 2 : 1, prev = (k - step + rt_scene::PIPE_SLOTS) % rt_scene::PIPE_SLOTS;
+        if (s->pipe_pending >= step && !s->pipe_harvested[prev]) {
+            s->pipe_rc[prev] = w->wait();
+            s->pipe_err[prev] = w->err;
+            s->pipe_harvested[prev] = true;
+        }
+    }
+    const rt_camera_desc cam_v = *cam;
+    rt_render_opts opts_v = *opts;
+    opts_v.stream = nullptr;  // (a caller stream would have to be ordered against the other slot's by the caller)
+    const int device = s->device;
+    hipStream_t copy_stream = s->copy_stream;
+    hipEvent_t rendered = host ? s->pipe_rendered[k] : nullptr, copied = host ? s->pipe_copied[k] : nullptr, ready = s->pipe_ready[k];
+    hipStream_t st = rs == s ? s->pipe_stream : rs->stream;
+    w->start([=]() -> int {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { rt_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e)); return RT_ERR_HIP; }
+        t_plain_enqueue = true;
+        HIP_TRY(hipStreamWaitEvent(st, ready, 0));
+        int r = clear_frame_border(st, &cam_v, d_rgb, d_id, d_fl);
+        if (r != RT_OK) return r;
+        CameraParams c;
+        long long n_slots = 0;
+        r = render_shard_impl(rs, &cam_v, &opts_v, st, d_rgb, d_id, d_fl, nullptr, c, n_slots, true);
+        if (r != RT_OK) return r;
+        if (!host) {
+            HIP_TRY(hipStreamSynchronize(st));
+            return RT_OK;
+        }
+        HIP_TRY(hipEventRecord(rendered, st));
+        HIP_TRY(hipStreamWaitEvent(copy_stream, rendered, 0));
+        HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, copy_stream));
+        if (hit_id_out) HIP_TRY(hipMemcpyAsync(hit_id_out, d_id, npx * sizeof(int32_t), hipMemcpyDeviceToHost, copy_stream));
+        if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, d_fl, npx, hipMemcpyDeviceToHost, copy_stream));
+        HIP_TRY(hipEventRecord(copied, copy_stream));
+        return RT_OK;  // (rt_render_end waits for the copy: this slot's stream and queues are free for the next frame now)
+    });
+    s->pipe_host[k] = host;
+    s->pipe_harvested[k] = false;
+    s->pipe_head = (k + 1) % rt_scene::PIPE_SLOTS;
     s->pipe_pending++;
     return RT_OK;
 }
 
+int rt_render_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
+                    uint8_t* flags_out) {
+    return pipe_begin(s, cam, opts, true, rgb_out, hit_id_out, flags_out, "rt_render_begin");
+}
+
+int rt_render_frame_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
+                          uint8_t* d_flags_frame) {
+    return pipe_begin(s, cam, opts, false, d_rgb_frame, d_hit_id_frame, d_flags_frame, "rt_render_frame_begin");
+}
+
 int rt_render_end(rt_scene* s) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!check_scene(s, true)) return RT_ERR_BAD_ARG;
     if (s->pipe_pending == 0) return RT_OK;  // nothing in flight
-    const int k = s->pipe_pending == 2 ? s->pipe_head : s->pipe_head ^ 1;  // the oldest frame begun and not yet retired
-    HIP_TRY(hipEventSynchronize(s->pipe_copied[k]));
+    const int k = (s->pipe_head - s->pipe_pending + rt_scene::PIPE_SLOTS) % rt_scene::PIPE_SLOTS;  // the oldest frame begun and not yet retired
+    Worker* w = s->pipe_worker[s->twin ? (k & 1) : 0];
+    int rc = RT_OK;
+    if (s->pipe_harvested[k]) {  // its lane has been given a later frame since
+        rc = s->pipe_rc[k];
+        s->pipe_harvested[k] = false;
+        if (rc != RT_OK) rt_set_error("%s", s->pipe_err[k].c_str());
+    } else if (w) {
+        rc = w->wait();
+        if (rc != RT_OK) rt_set_error("%s", w->err.c_str());
+    }
     s->pipe_pending--;
-    return RT_OK;
+    if (rc == RT_OK && s->pipe_host[k] && s->pipe_copied[k] && hipEventSynchronize(s->pipe_copied[k]) != hipSuccess) {
+        rt_set_error("the copy of a frame to the host failed: %s", hipGetErrorString(hipGetLastError()));
+        return RT_ERR_HIP;
+    }
+    return rc;
 }
 
 int rt_scene_create_multi(const rt_scene_desc* desc, int32_t n_gpus, const int32_t* devices, rt_scene** out) {

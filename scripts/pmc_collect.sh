@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $root/gpurun_out/pmc_${tag}_$c
-  timeout -s KILL 170 rocprofv3 --pmc $c --output-format csv -d $root/gpurun_out/pmc_${tag}_$c -- python3 $root/bench.py --traffic file "$@" > $root/gpurun_out/pmc_${tag}_$c.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc $c --output-format csv -d $root/gpurun_out/pmc_${tag}_$c -- python3 $root/bench.py --traffic file --in-flight 1 "$@" > $root/gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 cd $root
 python scripts/pmc_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}.json "$*" $hs $vs

@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $root/gpurun_out/${tag}_prof
-timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --no-cpu-baseline --no-c5 --traffic file > $root/gpurun_out/${tag}_bench_under_rocprof.json 2> $root/gpurun_out/${tag}_prof.err
+timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --no-cpu-baseline --no-c5 --traffic file --in-flight 1 > $root/gpurun_out/${tag}_bench_under_rocprof.json 2> $root/gpurun_out/${tag}_prof.err
 cd $root
 bash scripts/pmc_collect.sh $tag 1920 1080 --steps 2 --warmup 1 --no-cpu-baseline --no-c5
 cp gpurun_out/pmc_${tag}.json profiles/pmc_traffic.json   # what the bench line below quotes as roofline.traffic

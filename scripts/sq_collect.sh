@@ -16,7 +16,7 @@ for p in "$p1" "$p2" "$p3"; do
   i=$((i+1))
   d=$root/gpurun_out/${tag}_sq_$i
   rm -rf $d
-  timeout -s KILL 170 rocprofv3 --pmc $p --output-format csv -d $d -o p -- python3 $root/bench.py --traffic file --steps 2 --warmup 1 --no-cpu-baseline --no-c5 > $d.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc $p --output-format csv -d $d -o p -- python3 $root/bench.py --traffic file --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-c5 > $d.log 2>&1
   dirs="$dirs $(dirname $(find $d -name 'p_counter_collection.csv' | head -1))"
 done
 cd $root

@@ -1441,15 +1441,54 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
             r, i, f = bufs[(k - 1) & 1]
             want = refs[((k - 1) // 2) & 1]
             assert np.array_equal(r, want.rgb) and np.array_equal(i, want.hit_id) and np.array_equal(f, want.flags), k
-    # a third frame in flight is refused, and the two in flight still complete
-    for k in range(2):
-        assert rt.lib.rt_render_begin(scene, C.byref(cams[k]), C.byref(opts), bufs[k][0].ctypes.data_as(rt.c_dp), None, None) == 0
-    assert rt.lib.rt_render_begin(scene, C.byref(cams[0]), C.byref(opts), bufs[0][0].ctypes.data_as(rt.c_dp), None, None) == rt.RT_ERR_BAD_ARG
-    assert rt.lib.rt_render_end(scene) == 0 and rt.lib.rt_render_end(scene) == 0 and rt.lib.rt_render_end(scene) == 0
-    assert np.array_equal(bufs[0][0], ref.rgb) and np.array_equal(bufs[1][0], ref2.rgb)
+    # four frames in flight (two being rendered, two being copied); a fifth is refused, and the four still complete
+    more = [rt.pinned_array((cam.vsize, cam.hsize, 3)) for _ in range(4)]
+    for rounds in range(3):
+        for k in range(4):
+            more[k][...] = -1.
+            assert rt.lib.rt_render_begin(scene, C.byref(cams[k & 1]), C.byref(opts), more[k].ctypes.data_as(rt.c_dp), None, None) == 0, rt.last_error()
+        assert rt.lib.rt_render_begin(scene, C.byref(cams[0]), C.byref(opts), bufs[0][0].ctypes.data_as(rt.c_dp), None, None) == rt.RT_ERR_BAD_ARG
+        for k in range(4):
+            assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+            assert np.array_equal(more[k], refs[k & 1].rgb), (rounds, k)
+        assert rt.lib.rt_render_end(scene) == 0
+    # a steady state of three in flight
+    for k in range(11):
+        if k < 8:
+            more[k % 4][...] = -1.
+            assert rt.lib.rt_render_begin(scene, C.byref(cams[(k // 3) & 1]), C.byref(opts), more[k % 4].ctypes.data_as(rt.c_dp), None, None) == 0, rt.last_error()
+        if k >= 3:
+            assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+            assert np.array_equal(more[(k - 3) % 4], refs[((k - 3) // 3) & 1].rgb), k
+    assert rt.lib.rt_render_end(scene) == 0
     # and rt_render still works on the same scene afterwards
     assert rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), ids.ctypes.data_as(rt.c_ip), None, None) == 0
     assert np.array_equal(rgb, ref.rgb)
+    # rt_render_frame_begin: two frames in flight, each left in a DEVICE frame of the caller's (round 3: the two are rendered
+    # side by side, the second by the scene's twin); another call on the scene in between waits for them by itself
+    import torch
+    dev = [(torch.full((cam.vsize, cam.hsize, 3), -1., dtype=torch.float64, device="cuda:0"),
+            torch.full((cam.vsize, cam.hsize), -1, dtype=torch.int32, device="cuda:0"),
+            torch.full((cam.vsize, cam.hsize), 255, dtype=torch.uint8, device="cuda:0")) for _ in range(2)]
+    for k in range(9):
+        if k < 8:
+            r, i, f = dev[k & 1]
+            r.fill_(-1.)
+            torch.cuda.synchronize()
+            assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[(k // 2) & 1]), C.byref(opts), r.data_ptr(), i.data_ptr(), f.data_ptr()) == 0, rt.last_error()
+        if k == 4:   # a blocking call in the middle: it must wait for the frames in flight, not trample their queues
+            assert rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), None, None, None) == 0
+            assert np.array_equal(rgb, ref.rgb)
+        if k >= 1:
+            assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+            r, i, f = dev[(k - 1) & 1]
+            want = refs[((k - 1) // 2) & 1]
+            assert np.array_equal(r.cpu().numpy(), want.rgb) and np.array_equal(i.cpu().numpy(), want.hit_id) and np.array_equal(f.cpu().numpy(), want.flags), k
+    assert rt.lib.rt_render_end(scene) == 0
+    # an error inside a frame's render comes back from the rt_render_end that retires it
+    bad = rt.RenderOpts(max_depth=5, rank=0, n_ranks=1, want_counters=0, stream=None)
+    assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[0]), C.byref(bad), None, None, None) == rt.RT_ERR_BAD_ARG
+    assert rt.lib.rt_render_end(scene) == 0
     p = C.c_void_p()
     assert rt.lib.rt_host_alloc(0, C.byref(p)) == 0 and p.value
     rt.lib.rt_host_free(p)
