@@ -152,6 +152,7 @@ struct rt_scene {
     struct Worker* pipe_worker[2] = {nullptr, nullptr};
     hipStream_t pipe_stream = nullptr;
     hipEvent_t pipe_ready[PIPE_SLOTS] = {};
+    hipStream_t pipe_copy_stream[PIPE_SLOTS] = {};
     bool pipe_host[PIPE_SLOTS] = {};  // the slot's frame in flight goes to host buffers (rt_render_end waits for its copy)
     // a lane's host thread runs one job at a time: before it is given the next frame, the result of the one it has just
     // finished is put aside here for the rt_render_end that retires that frame
@@ -580,7 +581,8 @@ struct FixScope {
     }
 };
 
-int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats);
+int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats,
+                       const OutArgs* out = nullptr);
 
 // Level 0 (n0 rays, resolved, the stream waited for) holds `n_fix` rays flagged RT_FLAG_LIST_OVERFLOW: trace those
 // again with lists that are large enough and patch their colour, hit and flags back into level 0.  With `stats` the ray
@@ -634,27 +636,34 @@ int fix_overflowed_rays(rt_scene* s, hipStream_t st, long long n0, long long n_f
     return RT_OK;
 }
 
-int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats) {
-    return counters ? enqueue_levels<true>(s, st, n0, D, sync, tm, stats) : enqueue_levels<false>(s, st, n0, D, sync, tm, stats);
+int enqueue_levels_any(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, bool counters, Timer& tm, rt_stats* stats,
+                       const OutArgs* out) {
+    return counters ? enqueue_levels<true>(s, st, n0, D, sync, tm, stats, out) : enqueue_levels<false>(s, st, n0, D, sync, tm, stats, out);
 }
 
 // color_at for every ray already sitting in level 0 (n0 slots), complete when it returns: the whole tree enqueued at
 // once when the queues exist, else (or when one overflowed) the level-by-level walk that sizes them.
-int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, rt_stats* stats) {
+// `out` / `wrote`: level 0's shading pass may write the shard / frame itself (as on the graph path); *wrote says whether
+// it did — not when a queue overflowed or rays had to be traced again, then the caller's k_output does it.
+int run_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool counters, rt_stats* stats, const OutArgs* out = nullptr,
+               bool* wrote = nullptr) {
+    if (wrote) *wrote = false;
     if (D < 0) D = 0;  // color_at with remaining <= 0 still traces and shades the ray itself (src/world.rs:81-90)
     if (!s->spawns) D = 0;  // no material reflects or refracts: levels 1.. would be empty launches (a third of C2's frame)
     int rc = ensure_counters(s, D + 2);
     if (rc != RT_OK) return rc;
     Timer tm{s, st, stats != nullptr};
     if (levels_sized(s, D)) {
-        rc = enqueue_levels_any(s, st, n0, D, false, counters, tm, stats);
+        rc = enqueue_levels_any(s, st, n0, D, false, counters, tm, stats, out);
         if (rc != RT_OK) return rc;
         HIP_TRY(hipStreamSynchronize(st));
         if (!levels_overflowed(s, D)) {
             tm.collect();
             fill_stats(s, D, stats);
             const long long n_fix = (long long)s->h_counters[CNT_OVERFLOW];
-            return n_fix > 0 ? fix_overflowed_rays(s, st, n0, n_fix, D, stats) : RT_OK;
+            if (n_fix > 0) return fix_overflowed_rays(s, st, n0, n_fix, D, stats);
+            if (wrote && out) *wrote = true;
+            return RT_OK;
         }
         if (stats) {  // start the accounting over
             const int64_t primary = stats->rays_primary;
@@ -918,9 +927,12 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     }
     raygen();
     if (stats) HIP_TRY(hipEventRecord(whole.r1, st));
-    rc = run_levels(s, st, n_slots, D, opts->want_counters != 0, stats);
+    // (frames in flight are enqueued plainly: level 0's shading pass writes the frame there as well)
+    const OutArgs fused_plain{d_rgb, d_id, d_flags, c, frame ? 1 : 0};
+    bool wrote = false;
+    rc = run_levels(s, st, n_slots, D, opts->want_counters != 0, stats, t_plain_enqueue && s->fuse_output && !stats ? &fused_plain : nullptr, &wrote);
     if (rc != RT_OK) return rc;
-    output();
+    if (!wrote) output();
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(whole.e1, st));
@@ -1473,8 +1485,10 @@ void rt_scene_destroy(rt_scene* s) {
     }
     if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
     if (s->pipe_stream) { (void)hipStreamSynchronize(s->pipe_stream); (void)hipStreamDestroy(s->pipe_stream); }
-    for (int k = 0; k < rt_scene::PIPE_SLOTS; ++k)
+    for (int k = 0; k < rt_scene::PIPE_SLOTS; ++k) {
         if (s->pipe_ready[k]) (void)hipEventDestroy(s->pipe_ready[k]);
+        if (s->pipe_copy_stream[k]) { (void)hipStreamSynchronize(s->pipe_copy_stream[k]); (void)hipStreamDestroy(s->pipe_copy_stream[k]); }
+    }
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     for (LevelStore& l : s->fix_levels)
         if (l.block) (void)hipFree(l.block);
@@ -1703,7 +1717,8 @@ static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     rt_render_opts opts_v = *opts;
     opts_v.stream = nullptr;  // (a caller stream would have to be ordered against the other slot's by the caller)
     const int device = s->device;
-    hipStream_t copy_stream = s->copy_stream;
+    if (host && !s->pipe_copy_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&s->pipe_copy_stream[k], hipStreamNonBlocking));
+    hipStream_t copy_stream = host ? s->pipe_copy_stream[k] : nullptr;  // a copy stream per slot: copies of two frames may run side by side
     hipEvent_t rendered = host ? s->pipe_rendered[k] : nullptr, copied = host ? s->pipe_copied[k] : nullptr, ready = s->pipe_ready[k];
     hipStream_t st = rs == s ? s->pipe_stream : rs->stream;
     w->start([=]() -> int {
