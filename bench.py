@@ -502,8 +502,8 @@ def main():
                     "peak_measured": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured": round(achieved / FP64_VALU_MEASURED_TFLOPS, 5),
                     "launches_per_frame": n_launch, "avg_launch_ms": round(ms[dom] / n_launch, 5),
                     "source": "HIP events on the launch stream around every launch of %d rt_stats frames; those frames run "
-                              "the same launch schedule as the timed frames (plain enqueue where the timed frames replay "
-                              "it as one HIP graph), no host wait between launches" % n_ev,
+                              "the launch schedule of a timed frame, one frame at a time and with no host wait between launches; "
+                              "with two frames in flight the same launches overlap the other frame's and last longer each" % n_ev,
                     "flops_source": "work counters of one instrumented frame (want_counters=1) x SURVEY 8(d) constants",
                     "traffic_source": traffic_source,
                     "algorithmic_flops_per_launch": int(flops[dom] / n_launch),
