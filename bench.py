@@ -218,8 +218,9 @@ def main():
         # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
         # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
         # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
-        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(2 if sharded else 0)]
-        gather_done = [None, None]
+        # (four with shards in flight: two being rendered, one being gathered, one free)
+        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(4 if sharded else 0)]
+        gather_done = [None] * 4
         frame = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
         frame_b = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if not sharded else None  # second frame in flight
         # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
@@ -227,7 +228,7 @@ def main():
         gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
         u8 = sharded and args.gather == "u8"
         if u8:   # scale_color per rank before the gather (src/canvas.rs:86-98): 8x fewer bytes over xGMI; the root keeps a u8 frame
-            shards_q = [torch.zeros((n_max, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+            shards_q = [torch.zeros((n_max, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
             gathered_all = torch.zeros((world, n_max, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
             gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
             frame = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -300,8 +301,79 @@ def main():
                 if rt.lib.rt_render_end(scene) < 0:
                     raise RuntimeError(rt.last_error())
 
+        comm_stream = torch.cuda.Stream(dev) if sharded else None   # non-blocking: the render slots do not wait for a gather
+
+        def post(b):
+            """shard buffer b is complete in HBM: [quantise,] gather to rank 0 and scatter into the frame, enqueued on the
+            communication stream; the event behind them frees the buffer"""
+            with torch.cuda.stream(comm_stream):
+                cs = C.c_void_p(comm_stream.cuda_stream)
+                send = shards[b]
+                if u8:
+                    if rt.lib.rt_quantise(scene, shards[b].data_ptr(), n_max * 3, shards_q[b].data_ptr(), cs) < 0:
+                        raise RuntimeError(rt.last_error())
+                    send = shards_q[b]
+                dist.gather(send, gathered, dst=0)
+                if rank == 0:
+                    if u8:
+                        rc = rt.lib.rt_assemble_quantised(scene, C.byref(cd), world, gathered_all.data_ptr(), n_max, frame.data_ptr(), cs)
+                    else:
+                        rc = rt.lib.rt_assemble_strided(scene, C.byref(cd), world, gathered_all.data_ptr(), None, n_max, frame.data_ptr(), None, cs)
+                    if rc < 0:
+                        raise RuntimeError(rt.last_error())
+                ev = torch.cuda.Event()
+                ev.record()
+                gather_done[b] = ev
+
+        def shards_in_flight(n):
+            """n frames on the N > 1 path with this rank's shards two in flight (rt_render_shard_begin / rt_render_end, the two
+            rendered side by side like whole frames at N = 1): shard k is begun once shard k - 2 has been retired and handed to
+            its gather; the gather and scatter of a frame run on a stream of their own beside the renders.  Every rank takes
+            the same steps in the same order, so the collectives match; all n frames are assembled on rank 0 once the
+            device is idle (the caller's barrier + synchronize)."""
+            for g in gather_done:
+                if g is not None:
+                    g.synchronize()
+            for k in range(n):
+                if k >= 2 and rt.lib.rt_render_end(scene) < 0:
+                    raise RuntimeError(rt.last_error())
+                b = k & 3
+                if gather_done[b] is not None:
+                    gather_done[b].synchronize()      # the gather that read this buffer four frames ago
+                if rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None) < 0:
+                    raise RuntimeError(rt.last_error())
+                if k >= 2:                            # (after the begin: the render slot that has just come free is busy again
+                    post((k - 2) & 3)                 # while this thread enqueues the gather and the scatter)
+            for k in range(max(n - 2, 0), n):
+                if rt.lib.rt_render_end(scene) < 0:
+                    raise RuntimeError(rt.last_error())
+                post(k & 3)
+            state["k"] = 0
+
+        def verify():
+            """untimed, every rank calls it: three more frames through the shards-in-flight path, then rank 0 renders the WHOLE
+            frame by itself (rt_render_frame, rank 0 of 1) and compares it bit for bit with what the gather + scatter left
+            there (u8 gather: with scale_color of it) — a pixel's value must not depend on the partition (src/camera.rs:65-71)"""
+            if not sharded:
+                return None
+            shards_in_flight(3)
+            barrier()
+            if rank != 0:
+                return None
+            whole = torch.full((height, width, 3), -1., dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            o1 = rt.RenderOpts(max_depth=depth, rank=0, n_ranks=1, want_counters=0, stream=None)
+            if rt.lib.rt_render_frame(scene, C.byref(cd), C.byref(o1), whole.data_ptr(), None, None, None) < 0:
+                raise RuntimeError(rt.last_error())
+            if u8:
+                q = torch.empty((height, width, 3), dtype=torch.uint8, device=dev)
+                if rt.lib.rt_quantise(scene, whole.data_ptr(), height * width * 3, q.data_ptr(), None) < 0:
+                    raise RuntimeError(rt.last_error())
+                return bool(torch.equal(q, frame))
+            return bool(torch.equal(whole.view(torch.int64), frame.view(torch.int64)))
+
         return {"step": step, "scene": scene, "cd": cd, "opts": opts, "world_obj": w, "keep": (shards, frame, frame_b, gathered_all), "frame": frame,
-                "frames_in_flight": None if sharded else frames_in_flight}
+                "frames_in_flight": shards_in_flight if sharded else frames_in_flight, "verify": verify}
 
     def sharded_report(step, frames=5):
         """Per-rank phase times of the sharded path, a few untimed frames each waited for: what the first real N > 1 run needs
@@ -360,7 +432,7 @@ def main():
     w, cam = builders[args.scene](args.width, args.height)
     job = make_job(w, cam, args.depth, args.width, args.height)
     step, scene, cd, opts = job["step"], job["scene"], job["cd"], job["opts"]
-    piped = args.in_flight == 2 and not sharded
+    piped = args.in_flight == 2
     ms_per_step = timed(step, args.steps, args.warmup, job["frames_in_flight"] if piped else None)
     # one frame at a time (the latency of a frame; what `value` was until round 3's last step), beside the pipelined rate
     ms_single = timed(step, min(args.steps, 100), 3) if piped else ms_per_step
@@ -418,6 +490,9 @@ def main():
     opts.want_counters = 0
     total_rays = sum(rays[:4])
     sharded_info = sharded_report(step)
+    same = job["verify"]()
+    if sharded_info is not None:
+        sharded_info["assembled_frame_equals_whole_frame_render"] = same
 
     # ---- second workload, for the scaling sweep (the driver runs this file at N = 1, 2, 4, 8 with default arguments):
     # a 1.8 ms frame cannot scale across GPUs (launch floors and the gather dominate), C5 can.  Reported beside the
@@ -437,6 +512,10 @@ def main():
                     "steps": 20, "warmup": 4, "rays_per_frame": sum(rays5[:4]), "n_gpus": world, "frames_in_flight": 2 if piped else 1,
                     "one_frame_at_a_time": {"ms_per_frame": round(ms5_single, 4), "Mrays_s": round(sum(rays5[:4]) / (ms5_single * 1e-3) / 1e6, 3)},
                     "sharded": sharded_report(job5["step"], 3)}
+            same5 = job5["verify"]()
+            if out5["sharded"] is not None:
+                out5["sharded"]["assembled_frame_equals_whole_frame_render"] = same5
+            torch.cuda.synchronize()
             w5.invalidate()
             del job5
             return out5
@@ -560,7 +639,14 @@ def main():
                           "parallelism": "tile-shard x%d, RCCL gather" % world if sharded else "single GPU"},
                "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
                                   "total": total_rays, "shaded_nodes": rays[4]},
-               "value_is": ("rt_render_frame_begin / rt_render_end: Camera::render frame after frame with the Canvas left in HBM "
+               "value_is": ("rt_render_shard_begin / rt_render_end on every rank: Camera::render frame after frame, the frame cut into 8x8 "
+                            "tiles dealt round-robin to the ranks, each rank's shards TWO in flight (rendered side by side on two streams, "
+                            "a shard's launch tails filled by the next frame's shard), every retired shard gathered to rank 0 (RCCL, "
+                            "one gather per frame) and scattered into the row-major frame in HBM on a communication stream beside the "
+                            "renders; all K frames are assembled on rank 0 inside the timed region (barrier + device synchronize on both "
+                            "sides, max over ranks).  `one_frame_at_a_time`: one blocking rt_render_shard per frame and rank, then the "
+                            "gather (what this path timed until round 3's last step)" if (piped and sharded) else
+                            "rt_render_frame_begin / rt_render_end: Camera::render frame after frame with the Canvas left in HBM "
                             "(row-major f64), TWO frames in flight — rendered side by side on two streams, a frame's launch tails "
                             "filled by the other frame's launches; all K frames are complete inside the timed region; scene resident "
                             "before it.  `one_frame_at_a_time` is the same frame with one blocking rt_render_frame per frame (a "

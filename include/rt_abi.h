@@ -348,6 +348,16 @@ int rt_render_frame_begin(rt_scene* scene, const rt_camera_desc* camera, const r
                           int32_t* d_hit_id_frame, uint8_t* d_flags_frame);
 int rt_render_end(rt_scene* scene);
 
+/* Camera::render's pixel loop (src/camera.rs:65-71) for ONE SHARD of the frame, frame after frame with two shards in
+ * flight: rt_render_shard's arguments and output (shard opts->rank of opts->n_ranks in shard-local pixel order, DEVICE
+ * buffers, opts->stream ignored), handed to the same two render slots as rt_render_frame_begin and retired by the same
+ * rt_render_end — when that returns the shard is complete in device memory and work enqueued on ANY stream afterwards (an
+ * RCCL gather, rt_assemble) may read it.  For one-process-per-GPU drivers that render a sequence of frames: a rank's
+ * shard of a 1920x1080 frame is nearly all launch tails, which the next frame's shard fills.
+ * Shards in flight must be different buffers. */
+int rt_render_shard_begin(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* d_rgb_out,
+                          int32_t* d_hit_id_out, uint8_t* d_flags_out);
+
 /* Number of pixels shard `rank` of `n_ranks` renders (8x8-pixel tiles of the (hsize-1)x(vsize-1) domain dealt
  * round-robin).  Negative on bad arguments. */
 int64_t rt_shard_pixel_count(const rt_camera_desc* camera, int32_t rank, int32_t n_ranks);

@@ -1571,7 +1571,9 @@ int rt_assemble(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const d
 
 int rt_assemble_strided(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const double* d_rgb_shards, const int32_t* d_id_shards,
                         int64_t shard_stride, double* d_rgb_frame, int32_t* d_id_frame, void* stream) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    // (on a caller's stream this touches nothing a frame in flight uses — no queue, no counter, not the scene's stream — so it
+    // does not wait for the renders in flight: a one-process-per-GPU driver scatters frame k while its shards of k + 1, k + 2 render)
+    if (!check_scene(s, stream != nullptr)) return RT_ERR_BAD_ARG;
     if (!cam || !d_rgb_shards || !d_rgb_frame) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
     if (shard_stride < 0) { rt_set_error("negative shard stride"); return RT_ERR_BAD_ARG; }
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
@@ -1599,7 +1601,7 @@ int rt_assemble_strided(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks,
 
 // Canvas::scale_color (src/canvas.rs:86-98) for n_values f64 channel values in device memory -> u8, on `stream`.
 int rt_quantise(rt_scene* s, const double* d_rgb, int64_t n_values, uint8_t* d_quantised_out, void* stream) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!check_scene(s, stream != nullptr)) return RT_ERR_BAD_ARG;  // (as rt_assemble_strided)
     if (n_values < 0 || (n_values > 0 && (!d_rgb || !d_quantised_out))) { rt_set_error("null argument or negative count"); return RT_ERR_BAD_ARG; }
     if (n_values == 0) return RT_OK;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
@@ -1612,7 +1614,7 @@ int rt_quantise(rt_scene* s, const double* d_rgb, int64_t n_values, uint8_t* d_q
 // rt_assemble_strided for quantised (u8 RGB) shards: what a gather of rt_quantise'd shard buffers leaves on the root.
 int rt_assemble_quantised(rt_scene* s, const rt_camera_desc* cam, int32_t n_ranks, const uint8_t* d_q_shards, int64_t shard_stride,
                           uint8_t* d_q_frame, void* stream) {
-    if (!check_scene(s)) return RT_ERR_BAD_ARG;
+    if (!check_scene(s, stream != nullptr)) return RT_ERR_BAD_ARG;  // (as rt_assemble_strided)
     if (!cam || !d_q_shards || !d_q_frame) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
     if (shard_stride < 0) { rt_set_error("negative shard stride"); return RT_ERR_BAD_ARG; }
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
@@ -1670,12 +1672,15 @@ int rt_render(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts
 // Camera::render (src/camera.rs:62-74) frame after frame, two frames in flight: see include/rt_abi.h and rt_scene::twin.
 // `host`: the frame goes to HOST buffers (rendered into one of the scene's two device frames, copied on the copy stream);
 // otherwise it is left in the caller's DEVICE frame.
-static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, bool host, double* rgb_out, int32_t* hit_id_out,
-                      uint8_t* flags_out, const char* who) {
+// `shard` (device output only): the output is shard opts->rank of opts->n_ranks in shard-local pixel order, as rt_render_shard
+// writes it — what a one-process-per-GPU driver hands to its gather.
+static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, bool host, bool shard, double* rgb_out,
+                      int32_t* hit_id_out, uint8_t* flags_out, const char* who) {
     if (!check_scene(s, true)) return RT_ERR_BAD_ARG;
     if (!opts || !rgb_out || !cam) { rt_set_error("null argument"); return RT_ERR_BAD_ARG; }
-    if (opts->n_ranks != 1 || opts->rank != 0) { rt_set_error("%s renders whole frames (rank 0 of 1)", who); return RT_ERR_BAD_ARG; }
+    if (!shard && (opts->n_ranks != 1 || opts->rank != 0)) { rt_set_error("%s renders whole frames (rank 0 of 1)", who); return RT_ERR_BAD_ARG; }
     if (cam->hsize < 1 || cam->vsize < 1) { rt_set_error("camera size must be positive"); return RT_ERR_BAD_ARG; }
+    if (shard && rt_shard_pixel_count(cam, opts->rank, opts->n_ranks) < 0) { rt_set_error("%s: bad camera size or shard", who); return RT_ERR_BAD_ARG; }
     if (s->pipe_pending >= rt_scene::PIPE_SLOTS) { rt_set_error("%d frames are in flight already: call rt_render_end first", rt_scene::PIPE_SLOTS); return RT_ERR_BAD_ARG; }
     const int k = s->pipe_head;
     const size_t npx = size_t(cam->hsize) * size_t(cam->vsize);
@@ -1726,11 +1731,11 @@ static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
         if (e != hipSuccess) { rt_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e)); return RT_ERR_HIP; }
         t_plain_enqueue = true;
         HIP_TRY(hipStreamWaitEvent(st, ready, 0));
-        int r = clear_frame_border(st, &cam_v, d_rgb, d_id, d_fl);
+        int r = shard ? RT_OK : clear_frame_border(st, &cam_v, d_rgb, d_id, d_fl);
         if (r != RT_OK) return r;
         CameraParams c;
         long long n_slots = 0;
-        r = render_shard_impl(rs, &cam_v, &opts_v, st, d_rgb, d_id, d_fl, nullptr, c, n_slots, true);
+        r = render_shard_impl(rs, &cam_v, &opts_v, st, d_rgb, d_id, d_fl, nullptr, c, n_slots, !shard);
         if (r != RT_OK) return r;
         if (!host) {
             HIP_TRY(hipStreamSynchronize(st));
@@ -1753,12 +1758,17 @@ static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
 
 int rt_render_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* rgb_out, int32_t* hit_id_out,
                     uint8_t* flags_out) {
-    return pipe_begin(s, cam, opts, true, rgb_out, hit_id_out, flags_out, "rt_render_begin");
+    return pipe_begin(s, cam, opts, true, false, rgb_out, hit_id_out, flags_out, "rt_render_begin");
 }
 
 int rt_render_frame_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_frame, int32_t* d_hit_id_frame,
                           uint8_t* d_flags_frame) {
-    return pipe_begin(s, cam, opts, false, d_rgb_frame, d_hit_id_frame, d_flags_frame, "rt_render_frame_begin");
+    return pipe_begin(s, cam, opts, false, false, d_rgb_frame, d_hit_id_frame, d_flags_frame, "rt_render_frame_begin");
+}
+
+int rt_render_shard_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_opts* opts, double* d_rgb_out, int32_t* d_hit_id_out,
+                          uint8_t* d_flags_out) {
+    return pipe_begin(s, cam, opts, false, true, d_rgb_out, d_hit_id_out, d_flags_out, "rt_render_shard_begin");
 }
 
 int rt_render_end(rt_scene* s) {

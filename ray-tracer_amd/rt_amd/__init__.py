@@ -164,7 +164,7 @@ class CMaterial(C.Structure):  # rth_material
 
 
 # ---- prototypes: every symbol include/*.h declares -------------------------------------------------------
-ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_begin", "rt_render_frame_begin", "rt_render_end", "rt_shard_pixel_count",
+ABI_SYMBOLS = ["rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_begin", "rt_render_frame_begin", "rt_render_shard_begin", "rt_render_end", "rt_shard_pixel_count",
                "rt_render_shard", "rt_scene_meshes_built_on_gpu", "rt_scene_meshes_shared", "rt_render_frame", "rt_assemble", "rt_assemble_strided", "rt_quantise", "rt_assemble_quantised", "rt_color_at", "rt_intersect_world", "rt_is_shadowed", "rt_prepare_computations", "rt_normal_at", "rt_lighting",
                "rt_ray_for_pixel", "rt_canvas_to_ppm", "rt_canvas_to_ppm_noalloc", "rt_scene_create_multi", "rt_scene_create_opts", "rt_render_multi", "rt_host_alloc", "rt_host_free",
                "rt_scene_gpu_count", "rt_scene_gather_kind", "rt_last_error"]
@@ -186,6 +186,7 @@ lib.rt_scene_destroy.restype = None
 lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp, C.POINTER(Stats)]
 lib.rt_render_begin.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), c_dp, c_ip, c_bp]
 lib.rt_render_frame_begin.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
+lib.rt_render_shard_begin.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]
 lib.rt_render_end.argtypes = [C.c_void_p]
 lib.rt_shard_pixel_count.argtypes = [C.POINTER(CameraDesc), C.c_int32, C.c_int32]
 lib.rt_shard_pixel_count.restype = C.c_int64

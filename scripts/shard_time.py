@@ -1,5 +1,6 @@
 """Times rt_render_shard for rank 0 of N = 1, 2, 4, 8 on ONE GPU (what each rank of an N-GPU run would spend rendering,
-gather excluded): the strong-scaling limit of the render itself."""
+gather excluded): the strong-scaling limit of the render itself.  Then the same shards two in flight
+(rt_render_shard_begin / rt_render_end), which is how bench.py's N > 1 path renders them."""
 import ctypes as C
 import os
 import sys
@@ -29,4 +30,20 @@ for n in (1, 2, 4, 8):
         rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), buf.data_ptr(), None, None, None)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / K * 1e3
-    print(f"rank 0 of {n}: {cnt} slots, {ms:.3f} ms per shard render")
+    bufs = [torch.zeros((cnt, 3), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+
+    def in_flight(k_frames):
+        for k in range(k_frames):
+            if k >= 2:
+                assert rt.lib.rt_render_end(scene) == 0
+            assert rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1].data_ptr(), None, None) == 0, rt.last_error()
+        for _ in range(min(k_frames, 2)):
+            assert rt.lib.rt_render_end(scene) == 0
+    in_flight(6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K2 = 60
+    in_flight(K2)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / K2 * 1e3
+    print(f"rank 0 of {n}: {cnt} slots, {ms:.3f} ms per shard render, {ms2:.3f} ms with two shards in flight", flush=True)

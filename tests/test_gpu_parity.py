@@ -1497,6 +1497,80 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
 
 
 @pytest.mark.gpu
+def test_shards_in_flight_are_the_shards_rt_render_shard_writes():
+    """rt_render_shard_begin / rt_render_end: a rank's shards of successive frames, two in flight (what bench.py's N > 1
+    path hands to its gather).  Every shard of a 3-way and a 2-way split, two cameras in turn, is bit-identical to the
+    blocking rt_render_shard's, ids and flags included, and the shards assemble (rt_assemble) into the frame
+    Camera::render gives (src/camera.rs:62-74); whole-frame begins and a blocking call share the slots in between."""
+    import torch
+    w, cam = scenes.teapot_scene(160, 90)
+    cam2 = scenes.teapot_scene(160, 90)[1]
+    cam2.transform = view_transform((2., 3.5, -7.), (0., 1., 0.), (0., 1., 0.))
+    refs = [cam.render(w), cam2.render(w)]
+    cams = [cam.desc(), cam2.desc()]
+    scene = w.scene()
+    for n_ranks in (3, 2):
+        counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cams[0]), r, n_ranks)) for r in range(n_ranks)]
+        n_max = max(counts)
+        # what the blocking call writes for every (camera, rank)
+        want = {}
+        for ci in range(2):
+            for r in range(n_ranks):
+                o = rt.RenderOpts(max_depth=5, rank=r, n_ranks=n_ranks, want_counters=0, stream=None)
+                rgb = torch.full((n_max, 3), -1., dtype=torch.float64, device="cuda:0")
+                ids = torch.full((n_max,), -1, dtype=torch.int32, device="cuda:0")
+                fl = torch.full((n_max,), 255, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                assert rt.lib.rt_render_shard(scene, C.byref(cams[ci]), C.byref(o), rgb.data_ptr(), ids.data_ptr(), fl.data_ptr(), None) == 0, rt.last_error()
+                want[ci, r] = (rgb.cpu().numpy(), ids.cpu().numpy(), fl.cpu().numpy())
+        # the same shards, two in flight: job k = (camera (k // 2) & 1, rank k % n_ranks), four buffers in turn
+        bufs = [(torch.empty((n_max, 3), dtype=torch.float64, device="cuda:0"), torch.empty((n_max,), dtype=torch.int32, device="cuda:0"),
+                 torch.empty((n_max,), dtype=torch.uint8, device="cuda:0")) for _ in range(4)]
+        jobs = [((k // 2) & 1, k % n_ranks) for k in range(12)]
+        got = {}
+        for k in range(len(jobs) + 2):
+            if k >= 2:
+                assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+                r_, i_, f_ = bufs[(k - 2) & 3]
+                a, b, c = want[jobs[k - 2]]
+                assert np.array_equal(r_.cpu().numpy(), a) and np.array_equal(i_.cpu().numpy(), b) and np.array_equal(f_.cpu().numpy(), c), (n_ranks, k - 2)
+                got[jobs[k - 2]] = r_.clone()
+            if k < len(jobs):
+                ci, r = jobs[k]
+                r_, i_, f_ = bufs[k & 3]
+                r_.fill_(-1.), i_.fill_(-1), f_.fill_(255)
+                torch.cuda.synchronize()
+                o = rt.RenderOpts(max_depth=5, rank=r, n_ranks=n_ranks, want_counters=0, stream=None)
+                assert rt.lib.rt_render_shard_begin(scene, C.byref(cams[ci]), C.byref(o), r_.data_ptr(), i_.data_ptr(), f_.data_ptr()) == 0, rt.last_error()
+            if k == 5:   # a blocking call in between waits for the shards in flight by itself
+                img = cam.render(w)
+                assert np.array_equal(img.rgb, refs[0].rgb)
+        assert rt.lib.rt_render_end(scene) == 0     # nothing left in flight
+        # the shards of one frame, back to back, scatter into Camera::render's frame
+        for ci in range(2):
+            cat = torch.cat([got[ci, r][: counts[r]] for r in range(n_ranks)])
+            frame = torch.full((cam.vsize, cam.hsize, 3), -1., dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            assert rt.lib.rt_assemble(scene, C.byref(cams[ci]), n_ranks, cat.data_ptr(), None, frame.data_ptr(), None, None) == 0, rt.last_error()
+            assert np.array_equal(frame.cpu().numpy(), refs[ci].rgb), (n_ranks, ci)
+    # a shard and a whole frame in flight together; a bad shard is refused at the begin
+    o = rt.RenderOpts(max_depth=5, rank=1, n_ranks=2, want_counters=0, stream=None)
+    whole = rt.RenderOpts(max_depth=5, rank=0, n_ranks=1, want_counters=0, stream=None)
+    frame = torch.full((cam.vsize, cam.hsize, 3), -1., dtype=torch.float64, device="cuda:0")
+    shard = torch.full((int(rt.lib.rt_shard_pixel_count(C.byref(cams[1]), 1, 2)), 3), -1., dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[0]), C.byref(whole), frame.data_ptr(), None, None) == 0, rt.last_error()
+    assert rt.lib.rt_render_shard_begin(scene, C.byref(cams[1]), C.byref(o), shard.data_ptr(), None, None) == 0, rt.last_error()
+    assert rt.lib.rt_render_end(scene) == 0 and rt.lib.rt_render_end(scene) == 0, rt.last_error()
+    assert np.array_equal(frame.cpu().numpy(), refs[0].rgb)
+    assert np.array_equal(shard.cpu().numpy(), want[1, 1][0][: shard.shape[0]])
+    bad = rt.RenderOpts(max_depth=5, rank=2, n_ranks=2, want_counters=0, stream=None)
+    assert rt.lib.rt_render_shard_begin(scene, C.byref(cams[0]), C.byref(bad), shard.data_ptr(), None, None) == rt.RT_ERR_BAD_ARG
+    assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[0]), C.byref(o), frame.data_ptr(), None, None) == rt.RT_ERR_BAD_ARG
+    assert rt.lib.rt_render_end(scene) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_built_bvh_on_awkward_meshes(seed):
     """rt_lbvh.hip against the host tree on meshes chosen to stress the radix tree: many triangles with one and the same
