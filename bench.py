@@ -20,6 +20,12 @@ import os
 import sys
 import time
 
+# Three frames in flight are rendered on three streams beside the caller's and the scene's own: the HIP runtime maps a process's
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other, so the
+# third render lane needs more queues than the default (include/rt_abi.h: rt_scene_opts.render_lanes).  Read by the runtime
+# when it starts: set before torch / the library are loaded; inherited by the rocprofv3 child runs.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -154,10 +160,11 @@ def main():
     ap.add_argument("--scene", default="teapot", choices=["teapot", "teapot_smooth", "teapot_low", "mixed", "book", "grid"])
     ap.add_argument("--grid", type=int, default=4, help="--scene grid: grid x grid teapots (13 = 1.07 M triangles, SURVEY 8(d) C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
-                    help="N = 1: frames in flight in the timed region.  2 (default): rt_render_frame_begin / rt_render_end, the frames "
-                         "rendered side by side on two streams (a frame's launch tails are filled by the other frame's launches); "
-                         "1: one blocking rt_render_frame per frame (what the profile scripts trace: launches not overlapped)")
+    ap.add_argument("--in-flight", type=int, default=3, choices=[1, 2, 3],
+                    help="frames (N > 1: this rank's shards) in flight in the timed region.  3 (default) or 2: rt_render_frame_begin / "
+                         "rt_render_shard_begin / rt_render_end, the frames rendered side by side on streams of their own (a frame's "
+                         "launch tails are filled by the other frames' launches); 1: one blocking rt_render_frame / rt_render_shard per "
+                         "frame (what the profile scripts trace: launches not overlapped)")
     ap.add_argument("--rehearse-sharded", action="store_true",
                     help="N = 1 only: take the N > 1 code path (rt_render_shard, RCCL gather in a one-rank group, rt_assemble_strided)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 workloads (grid 4 and grid 13 at 8K) reported beside the headline")
@@ -218,17 +225,18 @@ def main():
         # N > 1: two shard buffers used in turn, so that the RCCL gather of frame k (on torch's stream) overlaps the render
         # of frame k+1 (on the library's stream) with no host wait in between; a buffer is rendered into again only after
         # the gather that read it two frames earlier has finished (an event recorded behind that gather — by then long done)
-        # (four with shards in flight: two being rendered, one being gathered, one free)
-        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(4 if sharded else 0)]
-        gather_done = [None] * 4
+        # (six with shards in flight: up to three being rendered, one being gathered, two free)
+        NB, D = 6, max(args.in_flight, 1)
+        shards = [torch.zeros((n_max, 3), dtype=torch.float64, device=dev) for _ in range(NB if sharded else 0)]
+        gather_done = [None] * NB
         frame = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-        frame_b = torch.zeros((height, width, 3), dtype=torch.float64, device=dev) if not sharded else None  # second frame in flight
+        frame_b = [torch.zeros((height, width, 3), dtype=torch.float64, device=dev) for _ in range(2 if not sharded else 0)]  # frames in flight
         # the root gathers into one [world, n_max, 3] buffer: rt_assemble_strided reads the padded shards where they land
         gathered_all = torch.zeros((world, n_max, 3), dtype=torch.float64, device=dev) if (rank == 0 and sharded) else None
         gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
         u8 = sharded and args.gather == "u8"
         if u8:   # scale_color per rank before the gather (src/canvas.rs:86-98): 8x fewer bytes over xGMI; the root keeps a u8 frame
-            shards_q = [torch.zeros((n_max, 3), dtype=torch.uint8, device=dev) for _ in range(4)]
+            shards_q = [torch.zeros((n_max, 3), dtype=torch.uint8, device=dev) for _ in range(NB)]
             gathered_all = torch.zeros((world, n_max, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
             gathered = list(gathered_all.unbind(0)) if gathered_all is not None else None
             frame = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -289,15 +297,15 @@ def main():
                 phases["frames"] = phases.get("frames", 0) + 1
 
         def frames_in_flight(n):
-            """n frames, two in flight (one GPU): frame k is handed to rt_render_frame_begin as soon as frame k - 2 has been
+            """n frames, D in flight (one GPU): frame k is handed to rt_render_frame_begin as soon as frame k - D has been
             retired; every one of the n frames is complete in its device frame when this returns"""
-            bufs = (frame.data_ptr(), frame_b.data_ptr())
+            bufs = (frame.data_ptr(), frame_b[0].data_ptr(), frame_b[1].data_ptr())
             for k in range(n):
-                if k >= 2 and rt.lib.rt_render_end(scene) < 0:
+                if k >= D and rt.lib.rt_render_end(scene) < 0:
                     raise RuntimeError(rt.last_error())
-                if rt.lib.rt_render_frame_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1], None, None) < 0:
+                if rt.lib.rt_render_frame_begin(scene, C.byref(cd), C.byref(opts), bufs[k % D], None, None) < 0:
                     raise RuntimeError(rt.last_error())
-            for _ in range(min(n, 2)):
+            for _ in range(min(n, D)):
                 if rt.lib.rt_render_end(scene) < 0:
                     raise RuntimeError(rt.last_error())
 
@@ -326,8 +334,8 @@ def main():
                 gather_done[b] = ev
 
         def shards_in_flight(n):
-            """n frames on the N > 1 path with this rank's shards two in flight (rt_render_shard_begin / rt_render_end, the two
-            rendered side by side like whole frames at N = 1): shard k is begun once shard k - 2 has been retired and handed to
+            """n frames on the N > 1 path with this rank's shards D in flight (rt_render_shard_begin / rt_render_end, rendered
+            side by side like whole frames at N = 1): shard k is begun once shard k - D has been retired and handed to
             its gather; the gather and scatter of a frame run on a stream of their own beside the renders.  Every rank takes
             the same steps in the same order, so the collectives match; all n frames are assembled on rank 0 once the
             device is idle (the caller's barrier + synchronize)."""
@@ -335,19 +343,19 @@ def main():
                 if g is not None:
                     g.synchronize()
             for k in range(n):
-                if k >= 2 and rt.lib.rt_render_end(scene) < 0:
+                if k >= D and rt.lib.rt_render_end(scene) < 0:
                     raise RuntimeError(rt.last_error())
-                b = k & 3
+                b = k % NB
                 if gather_done[b] is not None:
-                    gather_done[b].synchronize()      # the gather that read this buffer four frames ago
+                    gather_done[b].synchronize()      # the gather that read this buffer six frames ago
                 if rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None) < 0:
                     raise RuntimeError(rt.last_error())
-                if k >= 2:                            # (after the begin: the render slot that has just come free is busy again
-                    post((k - 2) & 3)                 # while this thread enqueues the gather and the scatter)
-            for k in range(max(n - 2, 0), n):
+                if k >= D:                            # (after the begin: the render lane that has just come free is busy again
+                    post((k - D) % NB)                # while this thread enqueues the gather and the scatter)
+            for k in range(max(n - D, 0), n):
                 if rt.lib.rt_render_end(scene) < 0:
                     raise RuntimeError(rt.last_error())
-                post(k & 3)
+                post(k % NB)
             state["k"] = 0
 
         def verify():
@@ -432,7 +440,7 @@ def main():
     w, cam = builders[args.scene](args.width, args.height)
     job = make_job(w, cam, args.depth, args.width, args.height)
     step, scene, cd, opts = job["step"], job["scene"], job["cd"], job["opts"]
-    piped = args.in_flight == 2
+    piped = args.in_flight >= 2
     ms_per_step = timed(step, args.steps, args.warmup, job["frames_in_flight"] if piped else None)
     # one frame at a time (the latency of a frame; what `value` was until round 3's last step), beside the pipelined rate
     ms_single = timed(step, min(args.steps, 100), 3) if piped else ms_per_step
@@ -454,26 +462,30 @@ def main():
         host_ms = time_rt_render(rt.pinned_array((args.height, args.width, 3)))      # buffer from rt_host_alloc
         host_ms_pageable = time_rt_render(np.zeros((args.height, args.width, 3)))     # any malloc'ed buffer
 
-        def time_rt_render_pipelined():
-            """rt_render_begin / rt_render_end: the same frames into two page-locked host buffers used in turn, the D2H copy of
-            frame k on a copy stream while frame k + 1 is rendered; every frame is complete in host memory when its end returns"""
-            bufs = [rt.pinned_array((args.height, args.width, 3)) for _ in range(4)]
-            def run(n):   # four in flight: two being rendered (side by side), two being copied
+        host_bufs = [rt.pinned_array((args.height, args.width, 3)) for _ in range(6)]
+
+        def time_rt_render_pipelined(depth):
+            """rt_render_begin / rt_render_end: the same frames into page-locked host buffers used in turn, `depth` frames in
+            flight (some being rendered side by side, the others being copied on copy streams beside the renders); every frame
+            is complete in host memory when its end returns"""
+            def run(n):
                 for k in range(n):
-                    if k >= 4 and rt.lib.rt_render_end(scene) < 0:
+                    if k >= depth and rt.lib.rt_render_end(scene) < 0:
                         raise RuntimeError(rt.last_error())
-                    rc = rt.lib.rt_render_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 3].ctypes.data_as(rt.c_dp), None, None)
+                    rc = rt.lib.rt_render_begin(scene, C.byref(cd), C.byref(opts), host_bufs[k % depth].ctypes.data_as(rt.c_dp), None, None)
                     if rc < 0:
                         raise RuntimeError(rt.last_error())
-                for _ in range(min(n, 4)):
+                for _ in range(min(n, depth)):
                     if rt.lib.rt_render_end(scene) < 0:
                         raise RuntimeError(rt.last_error())
-            run(8)
+            run(2 * depth)
             n_host = max(6, min(args.steps, 40))
             t0 = time.perf_counter()
             run(n_host)
             return (time.perf_counter() - t0) / n_host * 1e3
-        host_ms_pipelined = time_rt_render_pipelined()
+        host_by_depth = {d: time_rt_render_pipelined(d) for d in (4, 6)}   # 4: what two render lanes could use; 6: three lanes
+        host_depth = min(host_by_depth, key=host_by_depth.get)
+        host_ms_pipelined = host_by_depth[host_depth]
 
     # ---- untimed: ray accounting, per-kernel HIP-event times, instrumented work counters (this rank's shard) ----
     st, rays = ray_counts(step)
@@ -509,7 +521,7 @@ def main():
             ms5_single = timed(job5["step"], 10, 2) if piped else ms5
             _, rays5 = ray_counts(job5["step"])
             out5 = {"workload": what, "ms_per_step": round(ms5, 4), "value": round(sum(rays5[:4]) / (ms5 * 1e-3) / 1e6, 3), "unit": "Mrays/s",
-                    "steps": 20, "warmup": 4, "rays_per_frame": sum(rays5[:4]), "n_gpus": world, "frames_in_flight": 2 if piped else 1,
+                    "steps": 20, "warmup": 4, "rays_per_frame": sum(rays5[:4]), "n_gpus": world, "frames_in_flight": args.in_flight,
                     "one_frame_at_a_time": {"ms_per_frame": round(ms5_single, 4), "Mrays_s": round(sum(rays5[:4]) / (ms5_single * 1e-3) / 1e6, 3)},
                     "sharded": sharded_report(job5["step"], 3)}
             same5 = job5["verify"]()
@@ -640,30 +652,32 @@ def main():
                "rays_per_frame": {"primary": rays[0], "reflect": rays[1], "refract": rays[2], "shadow": rays[3],
                                   "total": total_rays, "shaded_nodes": rays[4]},
                "value_is": ("rt_render_shard_begin / rt_render_end on every rank: Camera::render frame after frame, the frame cut into 8x8 "
-                            "tiles dealt round-robin to the ranks, each rank's shards TWO in flight (rendered side by side on two streams, "
+                            "tiles dealt round-robin to the ranks, each rank's shards %s in flight (rendered side by side on streams of their own, "
                             "a shard's launch tails filled by the next frame's shard), every retired shard gathered to rank 0 (RCCL, "
                             "one gather per frame) and scattered into the row-major frame in HBM on a communication stream beside the "
                             "renders; all K frames are assembled on rank 0 inside the timed region (barrier + device synchronize on both "
                             "sides, max over ranks).  `one_frame_at_a_time`: one blocking rt_render_shard per frame and rank, then the "
-                            "gather (what this path timed until round 3's last step)" if (piped and sharded) else
+                            "gather (what this path timed until round 3's last step)" % ("THREE" if args.in_flight == 3 else "TWO") if (piped and sharded) else
                             "rt_render_frame_begin / rt_render_end: Camera::render frame after frame with the Canvas left in HBM "
-                            "(row-major f64), TWO frames in flight — rendered side by side on two streams, a frame's launch tails "
-                            "filled by the other frame's launches; all K frames are complete inside the timed region; scene resident "
+                            "(row-major f64), %s frames in flight — rendered side by side on streams of their own, a frame's launch "
+                            "tails filled by the other frames' launches; all K frames are complete inside the timed region; scene resident "
                             "before it.  `one_frame_at_a_time` is the same frame with one blocking rt_render_frame per frame (a "
                             "frame's latency, and what `value` was up to round 3's r03b set); the roofline object is quoted on "
-                            "launches of such frames" if piped else
+                            "launches of such frames" % ("THREE" if args.in_flight == 3 else "TWO") if piped else
                             "rt_render_frame: Camera::render with the Canvas left in HBM (row-major f64), one blocking call per frame, "
                             "scene resident before the timed region"),
-               "frames_in_flight": 2 if piped else 1,
+               "frames_in_flight": args.in_flight,
                "one_frame_at_a_time": {"ms_per_frame": round(ms_single, 4), "Mrays_s": round(total_rays / (ms_single * 1e-3) / 1e6, 3)},
                "rt_render_host": None if host_ms is None else {
                    "ms_per_frame": round(host_ms_pipelined, 4), "Mrays_s": round(total_rays / (host_ms_pipelined * 1e-3) / 1e6, 3),
+                   "frames_in_flight": host_depth, "ms_per_frame_by_frames_in_flight": {str(d): round(v, 4) for d, v in host_by_depth.items()},
                    "ms_per_frame_blocking_rt_render": round(host_ms, 4),
                    "ms_per_frame_pageable_buffer": round(host_ms_pageable, 4),
                    "what": "SURVEY 8(d)'s wording of the metric — every frame complete in a HOST f64 buffer, the D2H copy of %.1f MB "
                            "included; PCIe-inclusive, so never `value`.  ms_per_frame: rt_render_begin / rt_render_end, frame "
-                           "after frame into four page-locked buffers (rt_host_alloc) used in turn, four frames in flight: two being "
-                           "rendered side by side, two being copied on a copy stream; ms_per_frame_blocking_rt_render: one rt_render call per frame "
+                           "after frame into page-locked buffers (rt_host_alloc) used in turn, timed with four and with six frames in "
+                           "flight (up to three being rendered side by side, the others being copied on copy streams) and quoted for the "
+                           "faster of the two (frames_in_flight); ms_per_frame_blocking_rt_render: one rt_render call per frame "
                            "(render, then copy) into a page-locked buffer; the last figure: rt_render into pageable memory"
                            % (args.height * args.width * 24 / 1e6)},
                "sharded": sharded_info,

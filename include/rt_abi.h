@@ -295,6 +295,12 @@ typedef struct rt_scene_opts {
     int32_t walk_bound;         /* the n1/n2 walk searches a mesh only as far back along the ray as a triangle there could still
                                    be the last container at the hit (worked out from the entries of the other shapes, which
                                    are listed first): -1/1 yes, 0 the whole line                       [RT_AMD_WALK_BOUND]    */
+    /* (struct_size >= 56) */
+    int32_t render_lanes;       /* rt_render_begin / rt_render_frame_begin / rt_render_shard_begin: how many frames in flight
+                                   are RENDERED side by side (each on a stream and on queues of its own): 1..3, or -1 for the
+                                   library's choice: 3 when the process runs with GPU_MAX_HW_QUEUES >= 6 (the HIP runtime's
+                                   variable: streams that share a hardware queue run one after the other, and with the
+                                   default 4 a third lane's stream shares one), else 2                  [RT_AMD_LANES]      */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is
@@ -322,25 +328,28 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
               int32_t* hit_id_out, uint8_t* flags_out, rt_stats* stats_out);
 
 /* Camera::render (src/camera.rs:62-74, which RETURNS a host Canvas) for callers that render frame after frame: the
- * same frame as rt_render into the same HOST buffers, with two frames in flight.  rt_render_begin hands the frame (whole
- * frames only: opts->rank 0 of 1, opts->stream ignored) to one of two render slots and returns; a slot renders into a
+ * same frame as rt_render into the same HOST buffers, with several frames in flight.  rt_render_begin hands the frame (whole
+ * frames only: opts->rank 0 of 1, opts->stream ignored) to one of the render lanes (three at most, rt_scene_opts.render_lanes) and returns; a lane renders into a
  * device frame of its own on a stream of its own and copies to rgb_out / hit_id_out / flags_out (the last two nullable) on a
- * copy stream; the buffers hold the frame once the matching rt_render_end has returned.  At most FOUR frames may be in
- * flight (two being rendered — frames are dealt to the two render slots in turn, and a begin waits for the render of the
- * frame two before it — and two being copied); rt_render_end retires the oldest one (and returns RT_OK at once when none
+ * copy stream; the buffers hold the frame once the matching rt_render_end has returned.  At most SIX frames may be in
+ * flight (with three lanes: three being rendered — frames are dealt to the render lanes in turn, and a begin waits for the
+ * render of the frame three before it — and three being copied); rt_render_end retires the oldest one (and returns RT_OK at once when none
  * is) and returns ITS result: an error of a frame's render surfaces there, not at its begin (rt_last_error has the text).
- *     begin(A); begin(B); begin(C); end() -> A complete; begin(D); end() -> B complete; begin(A'); ...
+ *     begin(A); begin(B); begin(C); begin(D); end() -> A complete; begin(E); end() -> B complete; begin(A'); ...
  * Round 2 overlapped the 0.85 ms copy of a 1920x1080 f64 frame with the next frame's render (2.5 -> 1.63 ms per frame at the
- * host); round 3 also renders the two frames side by side — each traversal launch ends in a tail of a few long rays during
- * which most of the chip is idle, and a launch of the OTHER frame's stream fills it — so a sequence of
- * frames comes out at 1.1-1.2 ms per frame where one frame alone takes 1.5.  The second slot is a shallow copy of the scene
- * made on first use: it shares the scene's read-only tables and owns its queues (about as much device memory again as the
- * scene's queues take).  Buffers from rt_host_alloc keep the copy off the critical path (a pageable buffer makes the
- * runtime stage it).  The caller must not touch a buffer between its begin and the end that retires it; any other call on
- * the scene first waits for the renders in flight.  rt_scene_destroy retires everything.
+ * host); round 3 also renders the frames in flight side by side — each traversal launch ends in a tail of a few long rays
+ * during which most of the chip is idle, and a launch of ANOTHER frame's stream fills it — so a
+ * sequence of frames comes out at 1.05-1.1 ms per frame where one frame alone takes 1.5 (two lanes: 1.1; three: 1.06; the
+ * smaller the frame, the more the third is worth: a rank's shard of an 8-way split 0.77 / 0.44 / 0.33 ms for one / two /
+ * three at once).  Lanes two and three are shallow copies of the scene made at the first begin: they share the scene's
+ * read-only tables and own their queues (each about as much device memory again as the scene's queues take, grown when the
+ * lane is first used; rt_scene_opts.render_lanes = 1 or 2 for fewer).  A caller that keeps fewer frames in flight uses as
+ * many lanes as it has frames in flight.  Buffers from rt_host_alloc keep the copy off the critical path (a pageable buffer
+ * makes the runtime stage it).  The caller must not touch a buffer between its begin and the end that retires it; any other
+ * call on the scene first waits for the renders in flight.  rt_scene_destroy retires everything.
  *
  * rt_render_frame_begin is the same with the Canvas left in DEVICE memory (rt_render_frame's arguments; frames in flight
- * must be different buffers; two in flight are all it can use); it shares the slots, and rt_render_end retires its frames
+ * must be different buffers; three in flight are all it can use); it shares the lanes, and rt_render_end retires its frames
  * too. */
 int rt_render_begin(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* rgb_out,
                     int32_t* hit_id_out, uint8_t* flags_out);
@@ -348,9 +357,9 @@ int rt_render_frame_begin(rt_scene* scene, const rt_camera_desc* camera, const r
                           int32_t* d_hit_id_frame, uint8_t* d_flags_frame);
 int rt_render_end(rt_scene* scene);
 
-/* Camera::render's pixel loop (src/camera.rs:65-71) for ONE SHARD of the frame, frame after frame with two shards in
- * flight: rt_render_shard's arguments and output (shard opts->rank of opts->n_ranks in shard-local pixel order, DEVICE
- * buffers, opts->stream ignored), handed to the same two render slots as rt_render_frame_begin and retired by the same
+/* Camera::render's pixel loop (src/camera.rs:65-71) for ONE SHARD of the frame, frame after frame with up to three shards
+ * in flight: rt_render_shard's arguments and output (shard opts->rank of opts->n_ranks in shard-local pixel order, DEVICE
+ * buffers, opts->stream ignored), handed to the same render lanes as rt_render_frame_begin and retired by the same
  * rt_render_end — when that returns the shard is complete in device memory and work enqueued on ANY stream afterwards (an
  * RCCL gather, rt_assemble) may read it.  For one-process-per-GPU drivers that render a sequence of frames: a rank's
  * shard of a 1920x1080 frame is nearly all launch tails, which the next frame's shard fills.

@@ -131,7 +131,9 @@ struct rt_scene {
     // rt_render_begin / rt_render_end: two device frames used in turn, the D2H copy of one on `copy_stream` while the
     // next is rendered on `stream`
     hipStream_t copy_stream = nullptr;
-    static constexpr int PIPE_SLOTS = 4;  // frames in flight at most: two being rendered (slot & 1 = the render lane), two being copied
+    static constexpr int PIPE_LANES = 3;  // render lanes at most: this scene and two twins (rt_scene_opts.render_lanes)
+    static constexpr int PIPE_SLOTS = 2 * PIPE_LANES;  // frames in flight at most: one being rendered and one being copied per lane
+                                                       // (slot % pipe_lanes = the render lane; 6 is a multiple of 1, 2 and 3)
     GrowBuf pipe_rgb[PIPE_SLOTS], pipe_id[PIPE_SLOTS], pipe_flags[PIPE_SLOTS];
     hipEvent_t pipe_rendered[PIPE_SLOTS] = {}, pipe_copied[PIPE_SLOTS] = {};
     int pipe_head = 0, pipe_pending = 0;  // next slot to use; frames begun and not yet retired (the most recent slots)
@@ -147,9 +149,11 @@ struct rt_scene {
     // blocking stream under capture.  What a blocking stream gives implicitly — work the caller enqueued on the default
     // stream before the call is done before the frame is written — is kept by an event recorded on the default stream at
     // the begin (`pipe_ready`), which the slot's stream waits for.
-    rt_scene* twin = nullptr;
-    bool is_twin = false, twin_failed = false;
-    struct Worker* pipe_worker[2] = {nullptr, nullptr};
+    rt_scene* twins[PIPE_LANES - 1] = {};
+    bool is_twin = false;
+    int max_lanes = PIPE_LANES;  // rt_scene_opts.render_lanes
+    int pipe_lanes = 0;          // lanes in use: fixed at the first begin (1 + the twins that could be made), 0 before
+    struct Worker* pipe_worker[PIPE_LANES] = {};
     hipStream_t pipe_stream = nullptr;
     hipEvent_t pipe_ready[PIPE_SLOTS] = {};
     hipStream_t pipe_copy_stream[PIPE_SLOTS] = {};
@@ -1083,12 +1087,12 @@ struct Worker {
 
 namespace {
 void wait_for_frames_in_flight(rt_scene* s) {
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < rt_scene::PIPE_LANES; ++k)
         if (s->pipe_worker[k]) (void)s->pipe_worker[k]->wait();
 }
 }  // namespace
 static void destroy_pipe_workers(rt_scene* s) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < rt_scene::PIPE_LANES; ++k) {
         delete s->pipe_worker[k];
         s->pipe_worker[k] = nullptr;
     }
@@ -1097,7 +1101,7 @@ static void destroy_pipe_workers(rt_scene* s) {
 // The scene that renders the second frame in flight (rt_scene::twin): shares every read-only table of `s` by pointer — the
 // tables are never written after creation — and owns what a frame writes.  Nothing here is undone on failure except the
 // twin itself: the caller then renders both slots on `s`, one after the other, as before.
-static int make_twin(rt_scene* s) {
+static int make_twin(rt_scene* s, int index) {
     std::unique_ptr<rt_scene, void (*)(rt_scene*)> t(new rt_scene(), [](rt_scene* x) { rt_scene_destroy(x); });
     t->is_twin = true;
     t->device = s->device;
@@ -1131,7 +1135,7 @@ static int make_twin(rt_scene* s) {
     int rc = ensure_counters(t.get(), 16);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&t->h_word), sizeof(long long), hipHostMallocDefault));
-    s->twin = t.release();
+    s->twins[index] = t.release();
     return RT_OK;
 }
 
@@ -1185,6 +1189,7 @@ struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
     bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true, general = false, walk_bound = true;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
+    int lanes = rt_scene::PIPE_LANES;  // render lanes of rt_render_begin and its siblings
 };
 void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     rt_scene_opts v;
@@ -1209,6 +1214,20 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     {   // 2: the tree, but every object left to the wavefront (no per-lane mesh instances)
         const char* e = std::getenv("RT_AMD_TLAS");
         k.tlas_instances = !(v.top_level_tree == 2 || (v.top_level_tree < 0 && e && std::atoi(e) == 2));
+    }
+    {
+        int n = v.render_lanes;
+        if (n < 1)
+            if (const char* e = std::getenv("RT_AMD_LANES")) n = std::atoi(e);
+        if (n < 1) {
+            // The library's choice: a lane only pays while its stream has a hardware queue to itself.  The HIP runtime spreads a
+            // process's streams over GPU_MAX_HW_QUEUES queues (4 unless the variable says otherwise) and streams that share one
+            // run one after the other: the caller's default stream, the scene's own and two lanes fill four; measured with a
+            // third lane, rank 0's shard of an 8-way split: 0.52 ms per shard at 4 queues (two lanes: 0.42), 0.32 at 8.
+            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+            n = (q && std::atoi(q) >= 6) ? rt_scene::PIPE_LANES : 2;
+        }
+        k.lanes = std::min(n, int(rt_scene::PIPE_LANES));
     }
     k.gather = v.gather == 1 || v.gather == 2 ? v.gather : -1;
     if (v.gather < 0)
@@ -1430,6 +1449,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
         return fail(RT_ERR_HIP);
     }
     s->use_graph = knobs.graph;
+    s->max_lanes = knobs.lanes;
     s->fuse_output = knobs.fuse_output;
     s->fuse_spawn = knobs.fuse_spawn;
     *out = s;
@@ -1470,7 +1490,8 @@ void rt_scene_destroy(rt_scene* s) {
     }
     (void)hipSetDevice(s->device);
     destroy_pipe_workers(s);  // joins the threads: nothing of a frame in flight is left running
-    if (s->twin) { rt_scene_destroy(s->twin); s->twin = nullptr; }
+    for (rt_scene*& t : s->twins)
+        if (t) { rt_scene_destroy(t); t = nullptr; }
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (void* p : s->allocs) (void)hipFree(p);
     for (LevelStore& l : s->levels)
@@ -1703,15 +1724,18 @@ static int pipe_begin(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     if (!s->pipe_stream) HIP_TRY(hipStreamCreateWithFlags(&s->pipe_stream, hipStreamNonBlocking));
     if (!s->pipe_ready[k]) HIP_TRY(hipEventCreateWithFlags(&s->pipe_ready[k], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(s->pipe_ready[k], nullptr));  // what the caller has enqueued on the default stream so far
-    if (!s->twin && !s->twin_failed && make_twin(s) != RT_OK) s->twin_failed = true;
-    // two render lanes, frames dealt to them in turn; without a twin there is one lane and the frames are rendered one after
-    // the other (their copies still overlap the renders)
-    const int lane = s->twin ? (k & 1) : 0;
-    rt_scene* rs = lane == 1 ? s->twin : s;
+    if (s->pipe_lanes == 0) {  // first begin on this scene: as many lanes as twins can be made (none: one lane, frames one after the other)
+        s->pipe_lanes = 1;
+        while (s->pipe_lanes < s->max_lanes && make_twin(s, s->pipe_lanes - 1) == RT_OK) s->pipe_lanes++;
+    }
+    // frames are dealt to the render lanes in turn (with one lane the frames are rendered one after the other; their copies
+    // still overlap the renders)
+    const int lanes = s->pipe_lanes, lane = k % lanes;
+    rt_scene* rs = lane == 0 ? s : s->twins[lane - 1];
     if (!s->pipe_worker[lane]) s->pipe_worker[lane] = new Worker();
     Worker* w = s->pipe_worker[lane];
     {   // the lane's previous frame, if it is still to be retired: wait for its render and put its result aside
-        const int step = s->twin ? 2 : 1, prev = (k - step + rt_scene::PIPE_SLOTS) % rt_scene::PIPE_SLOTS;
+        const int step = lanes, prev = (k - step + rt_scene::PIPE_SLOTS) % rt_scene::PIPE_SLOTS;
         if (s->pipe_pending >= step && !s->pipe_harvested[prev]) {
             s->pipe_rc[prev] = w->wait();
             s->pipe_err[prev] = w->err;
@@ -1775,7 +1799,7 @@ int rt_render_end(rt_scene* s) {
     if (!check_scene(s, true)) return RT_ERR_BAD_ARG;
     if (s->pipe_pending == 0) return RT_OK;  // nothing in flight
     const int k = (s->pipe_head - s->pipe_pending + rt_scene::PIPE_SLOTS) % rt_scene::PIPE_SLOTS;  // the oldest frame begun and not yet retired
-    Worker* w = s->pipe_worker[s->twin ? (k & 1) : 0];
+    Worker* w = s->pipe_worker[k % std::max(s->pipe_lanes, 1)];
     int rc = RT_OK;
     if (s->pipe_harvested[k]) {  // its lane has been given a later frame since
         rc = s->pipe_rc[k];

@@ -30,20 +30,22 @@ for n in (1, 2, 4, 8):
         rt.lib.rt_render_shard(scene, C.byref(cd), C.byref(opts), buf.data_ptr(), None, None, None)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / K * 1e3
-    bufs = [torch.zeros((cnt, 3), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    bufs = [torch.zeros((cnt, 3), dtype=torch.float64, device="cuda:0") for _ in range(3)]
 
-    def in_flight(k_frames):
+    def in_flight(k_frames, depth):
         for k in range(k_frames):
-            if k >= 2:
+            if k >= depth:
                 assert rt.lib.rt_render_end(scene) == 0
-            assert rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), bufs[k & 1].data_ptr(), None, None) == 0, rt.last_error()
-        for _ in range(min(k_frames, 2)):
+            assert rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), bufs[k % depth].data_ptr(), None, None) == 0, rt.last_error()
+        for _ in range(min(k_frames, depth)):
             assert rt.lib.rt_render_end(scene) == 0
-    in_flight(6)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    K2 = 60
-    in_flight(K2)
-    torch.cuda.synchronize()
-    ms2 = (time.perf_counter() - t0) / K2 * 1e3
-    print(f"rank 0 of {n}: {cnt} slots, {ms:.3f} ms per shard render, {ms2:.3f} ms with two shards in flight", flush=True)
+    res = []
+    for depth in (2, 3):
+        in_flight(6, depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K2 = 60
+        in_flight(K2, depth)
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0) / K2 * 1e3)
+    print(f"rank 0 of {n}: {cnt} slots, {ms:.3f} ms per shard render, {res[0]:.3f} ms with two shards in flight, {res[1]:.3f} with three", flush=True)

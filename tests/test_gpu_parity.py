@@ -1408,8 +1408,11 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
 
 
 @pytest.mark.gpu
-def test_rt_host_alloc_buffers_receive_the_same_frame():
-    """rt_host_alloc / rt_host_free: page-locked output buffers for rt_render are a faster target, not a different one."""
+@pytest.mark.parametrize("lanes", [3, 2, 1])
+def test_rt_host_alloc_buffers_receive_the_same_frame(monkeypatch, lanes):
+    """rt_host_alloc / rt_host_free: page-locked output buffers for rt_render are a faster target, not a different one;
+    frames in flight (rt_render_begin / rt_render_frame_begin / rt_render_end) on three, two and one render lanes."""
+    monkeypatch.setenv("RT_AMD_LANES", str(lanes))   # read at scene creation (rt_scene_opts.render_lanes)
     w, cam = scenes.teapot_scene(160, 90)
     ref = cam.render(w)
     rgb = rt.pinned_array((cam.vsize, cam.hsize, 3))
@@ -1441,26 +1444,29 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
             r, i, f = bufs[(k - 1) & 1]
             want = refs[((k - 1) // 2) & 1]
             assert np.array_equal(r, want.rgb) and np.array_equal(i, want.hit_id) and np.array_equal(f, want.flags), k
-    # four frames in flight (two being rendered, two being copied); a fifth is refused, and the four still complete
-    more = [rt.pinned_array((cam.vsize, cam.hsize, 3)) for _ in range(4)]
+    # six frames in flight (three being rendered side by side, three being copied); a seventh is refused, and the six still complete
+    more = [rt.pinned_array((cam.vsize, cam.hsize, 3)) for _ in range(6)]
     for rounds in range(3):
-        for k in range(4):
+        for k in range(6):
             more[k][...] = -1.
             assert rt.lib.rt_render_begin(scene, C.byref(cams[k & 1]), C.byref(opts), more[k].ctypes.data_as(rt.c_dp), None, None) == 0, rt.last_error()
         assert rt.lib.rt_render_begin(scene, C.byref(cams[0]), C.byref(opts), bufs[0][0].ctypes.data_as(rt.c_dp), None, None) == rt.RT_ERR_BAD_ARG
-        for k in range(4):
+        for k in range(6):
             assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
             assert np.array_equal(more[k], refs[k & 1].rgb), (rounds, k)
         assert rt.lib.rt_render_end(scene) == 0
-    # a steady state of three in flight
-    for k in range(11):
-        if k < 8:
-            more[k % 4][...] = -1.
-            assert rt.lib.rt_render_begin(scene, C.byref(cams[(k // 3) & 1]), C.byref(opts), more[k % 4].ctypes.data_as(rt.c_dp), None, None) == 0, rt.last_error()
-        if k >= 3:
-            assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
-            assert np.array_equal(more[(k - 3) % 4], refs[((k - 3) // 3) & 1].rgb), k
-    assert rt.lib.rt_render_end(scene) == 0
+    # steady states of three, four and five in flight
+    for depth_in_flight in (3, 4, 5):
+        n_frames = 13
+        for k in range(n_frames + depth_in_flight):
+            if k < n_frames:
+                more[k % 6][...] = -1.
+                assert rt.lib.rt_render_begin(scene, C.byref(cams[(k // 3) & 1]), C.byref(opts), more[k % 6].ctypes.data_as(rt.c_dp), None, None) == 0, rt.last_error()
+            if k >= depth_in_flight:
+                j = k - depth_in_flight
+                assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+                assert np.array_equal(more[j % 6], refs[(j // 3) & 1].rgb), (depth_in_flight, k)
+        assert rt.lib.rt_render_end(scene) == 0
     # and rt_render still works on the same scene afterwards
     assert rt.lib.rt_render(scene, C.byref(cd), C.byref(opts), rgb.ctypes.data_as(rt.c_dp), ids.ctypes.data_as(rt.c_ip), None, None) == 0
     assert np.array_equal(rgb, ref.rgb)
@@ -1469,7 +1475,7 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
     import torch
     dev = [(torch.full((cam.vsize, cam.hsize, 3), -1., dtype=torch.float64, device="cuda:0"),
             torch.full((cam.vsize, cam.hsize), -1, dtype=torch.int32, device="cuda:0"),
-            torch.full((cam.vsize, cam.hsize), 255, dtype=torch.uint8, device="cuda:0")) for _ in range(2)]
+            torch.full((cam.vsize, cam.hsize), 255, dtype=torch.uint8, device="cuda:0")) for _ in range(3)]
     for k in range(9):
         if k < 8:
             r, i, f = dev[k & 1]
@@ -1485,6 +1491,18 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
             want = refs[((k - 1) // 2) & 1]
             assert np.array_equal(r.cpu().numpy(), want.rgb) and np.array_equal(i.cpu().numpy(), want.hit_id) and np.array_equal(f.cpu().numpy(), want.flags), k
     assert rt.lib.rt_render_end(scene) == 0
+    # three device frames in flight: all three render lanes busy
+    for k in range(14):
+        if k >= 3:   # retire frame k - 3, then hand its buffer to frame k
+            assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+            r, i, f = dev[(k - 3) % 3]
+            want = refs[((k - 3) // 2) & 1]
+            assert np.array_equal(r.cpu().numpy(), want.rgb) and np.array_equal(i.cpu().numpy(), want.hit_id) and np.array_equal(f.cpu().numpy(), want.flags), k
+        if k < 11:
+            r, i, f = dev[k % 3]
+            r.fill_(-1.)   # (on torch's default stream: the begin orders the frame behind it)
+            assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[(k // 2) & 1]), C.byref(opts), r.data_ptr(), i.data_ptr(), f.data_ptr()) == 0, rt.last_error()
+    assert rt.lib.rt_render_end(scene) == 0
     # an error inside a frame's render comes back from the rt_render_end that retires it
     bad = rt.RenderOpts(max_depth=5, rank=0, n_ranks=1, want_counters=0, stream=None)
     assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[0]), C.byref(bad), None, None, None) == rt.RT_ERR_BAD_ARG
@@ -1497,19 +1515,20 @@ def test_rt_host_alloc_buffers_receive_the_same_frame():
 
 
 @pytest.mark.gpu
-def test_shards_in_flight_are_the_shards_rt_render_shard_writes():
-    """rt_render_shard_begin / rt_render_end: a rank's shards of successive frames, two in flight (what bench.py's N > 1
+def test_shards_in_flight_are_the_shards_rt_render_shard_writes(monkeypatch):
+    """rt_render_shard_begin / rt_render_end: a rank's shards of successive frames, two or three in flight (what bench.py's N > 1
     path hands to its gather).  Every shard of a 3-way and a 2-way split, two cameras in turn, is bit-identical to the
     blocking rt_render_shard's, ids and flags included, and the shards assemble (rt_assemble) into the frame
     Camera::render gives (src/camera.rs:62-74); whole-frame begins and a blocking call share the slots in between."""
     import torch
+    monkeypatch.setenv("RT_AMD_LANES", "3")   # all three render lanes, whatever GPU_MAX_HW_QUEUES says (read at scene creation)
     w, cam = scenes.teapot_scene(160, 90)
     cam2 = scenes.teapot_scene(160, 90)[1]
     cam2.transform = view_transform((2., 3.5, -7.), (0., 1., 0.), (0., 1., 0.))
     refs = [cam.render(w), cam2.render(w)]
     cams = [cam.desc(), cam2.desc()]
     scene = w.scene()
-    for n_ranks in (3, 2):
+    for n_ranks, depth_in_flight in ((3, 2), (2, 3)):
         counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cams[0]), r, n_ranks)) for r in range(n_ranks)]
         n_max = max(counts)
         # what the blocking call writes for every (camera, rank)
@@ -1523,21 +1542,22 @@ def test_shards_in_flight_are_the_shards_rt_render_shard_writes():
                 torch.cuda.synchronize()
                 assert rt.lib.rt_render_shard(scene, C.byref(cams[ci]), C.byref(o), rgb.data_ptr(), ids.data_ptr(), fl.data_ptr(), None) == 0, rt.last_error()
                 want[ci, r] = (rgb.cpu().numpy(), ids.cpu().numpy(), fl.cpu().numpy())
-        # the same shards, two in flight: job k = (camera (k // 2) & 1, rank k % n_ranks), four buffers in turn
+        # the same shards in flight: job k = (camera (k // 2) & 1, rank k % n_ranks), six buffers in turn
         bufs = [(torch.empty((n_max, 3), dtype=torch.float64, device="cuda:0"), torch.empty((n_max,), dtype=torch.int32, device="cuda:0"),
-                 torch.empty((n_max,), dtype=torch.uint8, device="cuda:0")) for _ in range(4)]
-        jobs = [((k // 2) & 1, k % n_ranks) for k in range(12)]
+                 torch.empty((n_max,), dtype=torch.uint8, device="cuda:0")) for _ in range(6)]
+        jobs = [((k // 2) & 1, k % n_ranks) for k in range(14)]
         got = {}
-        for k in range(len(jobs) + 2):
-            if k >= 2:
+        for k in range(len(jobs) + depth_in_flight):
+            if k >= depth_in_flight:
+                j = k - depth_in_flight
                 assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
-                r_, i_, f_ = bufs[(k - 2) & 3]
-                a, b, c = want[jobs[k - 2]]
-                assert np.array_equal(r_.cpu().numpy(), a) and np.array_equal(i_.cpu().numpy(), b) and np.array_equal(f_.cpu().numpy(), c), (n_ranks, k - 2)
-                got[jobs[k - 2]] = r_.clone()
+                r_, i_, f_ = bufs[j % 6]
+                a, b, c = want[jobs[j]]
+                assert np.array_equal(r_.cpu().numpy(), a) and np.array_equal(i_.cpu().numpy(), b) and np.array_equal(f_.cpu().numpy(), c), (n_ranks, j)
+                got[jobs[j]] = r_.clone()
             if k < len(jobs):
                 ci, r = jobs[k]
-                r_, i_, f_ = bufs[k & 3]
+                r_, i_, f_ = bufs[k % 6]
                 r_.fill_(-1.), i_.fill_(-1), f_.fill_(255)
                 torch.cuda.synchronize()
                 o = rt.RenderOpts(max_depth=5, rank=r, n_ranks=n_ranks, want_counters=0, stream=None)
