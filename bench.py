@@ -601,6 +601,19 @@ def main():
                     "algorithmic_bytes_per_launch": int(nbytes[dom] / n_launch),
                     "note": "f64 VALU-bound path, no MFMA (no dense contraction); peak = AMD FP64 vector spec / 2 because "
                             "reference parity forbids FMA contraction"}
+        # the whole frame at the rate `value` is quoted on (frames in flight fill each other's launch tails): every kernel's
+        # algorithmic flops per frame over the wall time per frame
+        frame_flops = float(sum(flops.values())) * (total_rays / max(sum(
+            [st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow]), 1))   # (N > 1: rank 0's shard scaled to the frame)
+        roofline["whole_frame"] = {
+            "algorithmic_flops_per_frame": int(frame_flops),
+            "at_value_rate": {"ms_per_frame": round(ms_per_step, 4), "achieved": round(frame_flops / (ms_per_step * 1e-3) / 1e12, 4),
+                              "frac": round(frame_flops / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 5)},
+            "one_frame_at_a_time": {"ms_per_frame": round(ms_single, 4), "achieved": round(frame_flops / (ms_single * 1e-3) / 1e12, 4),
+                                    "frac": round(frame_flops / (ms_single * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 5)},
+            "note": "all kernels' algorithmic flops of one frame / wall time per frame (launch gaps, queue compaction, shading and "
+                    "the idle tails included): `frac` above is the dominant kernel alone, timed launch by launch with one frame "
+                    "at a time"}
         # The HBM leg is priced on MEASURED traffic (PMC passes), never on algorithmic bytes: those count 128 B per BVH node
         # even when the node comes out of LDS and 80 B per triangle even when L2 serves it, so bytes / time can exceed what
         # HBM delivers.  No PMC file for this workload: null.

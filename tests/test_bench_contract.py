@@ -65,9 +65,9 @@ def test_sharded_bench_path_prints_one_json_line_too():
     for k in ("rank", "shard_ms", "gather_ms", "assemble_ms"):
         assert k in sh["per_rank"][0], k
     assert sh["per_rank"][0]["shard_ms"] > 0 and sh["per_rank"][0]["gather_ms"] >= 0 and sh["per_rank"][0]["assemble_ms"] > 0
-    # the timed region renders this rank's shards two in flight (rt_render_shard_begin); what the gather + scatter leave on rank 0
+    # the timed region renders this rank's shards three in flight (rt_render_shard_begin); what the gather + scatter leave on rank 0
     # is bit for bit the frame one whole-frame render gives
-    assert d["frames_in_flight"] == 2 and d["one_frame_at_a_time"]["ms_per_frame"] > 0
+    assert d["frames_in_flight"] == 3 and d["one_frame_at_a_time"]["ms_per_frame"] > 0
     assert sh["assembled_frame_equals_whole_frame_render"] is True
 
 
