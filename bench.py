@@ -40,6 +40,7 @@ F_PRIM = (38, 2, 18, 30, 36)                                # sphere, plane, cub
 F_PREPARE = 130       # prepare_computations with one parent level (60 + 70 per level)
 F_LIGHTING = 75       # Material::lighting per light (+ one powf)
 F_REFLECT, F_REFRACT, F_SCHLICK = 12, 25, 20
+F_RAYGEN = 80         # Camera::ray_for_pixel (src/camera.rs:37-60): two matrix * tuple products and a normalize
 B_BVH_NODE, B_MESH_TRI = 128, 80   # bytes fetched per BVH node / per triangle tested (rt_program.h)
 # bytes of level state read + written per ray by each stage (rt_device.h: Level columns touched)
 # (k_trace: a primary ray is read from its columns, 48; a ray of levels 1.. is made from its tag and its parent's hit,
@@ -551,11 +552,16 @@ def main():
         flops = {k: work_flops(v) for k, v in works.items()}
         flops["k_trace"] += st.shaded_nodes * F_PREPARE   # prepare_computations runs in k_trace's epilogue,
         flops["k_trace"] += st.rays_reflect * F_REFLECT + st.rays_refract * F_REFRACT   # the ray spawn where it fetches its rays
+        if os.environ.get("RT_AMD_FUSE_RAYGEN", "1") != "0":   # ... and ray_for_pixel for level 0's (rt_scene_opts.fuse_raygen, the default)
+            flops["k_trace"] += st.rays_primary * F_RAYGEN
         flops["k_queue"] = 0
         flops["k_shade"] = st.shaded_nodes * F_LIGHTING * n_lights + st.rays_refract * F_SCHLICK
         # (hits of levels 1.. are not counted apart: the spawned rays' share of the shaded nodes prices their stored rays)
         spawned_hits = st.shaded_nodes * spawned // max(traced, 1)
-        nbytes = {"k_trace": work_bytes(works["k_trace"]) + st.rays_primary * B_RAY_IO["k_trace"] + spawned * B_RAY_IO["k_trace_spawned"] +
+        fused_raygen = os.environ.get("RT_AMD_FUSE_RAYGEN", "1") != "0"
+        # (primary rays made by the launch that traces them: no 48-byte ray to read, and the ray is stored only with a hit)
+        primary_io = st.rays_primary * 17 + (st.shaded_nodes - spawned_hits) * 48 if fused_raygen else st.rays_primary * B_RAY_IO["k_trace"]
+        nbytes = {"k_trace": work_bytes(works["k_trace"]) + primary_io + spawned * B_RAY_IO["k_trace_spawned"] +
                   st.shaded_nodes * B_RAY_IO["k_trace_hit"] + spawned_hits * B_RAY_IO["k_trace_spawned_hit"] + st.rays_shadow * B_RAY_IO["shadow"],
                   "k_walk": work_bytes(works["k_walk"]) + st.rays_container * B_RAY_IO["container"],
                   "k_queue": traced * B_RAY_IO["k_queue"], "k_shade": traced * B_RAY_IO["k_shade"]}

@@ -301,6 +301,10 @@ typedef struct rt_scene_opts {
                                    library's choice: 3 when the process runs with GPU_MAX_HW_QUEUES >= 6 (the HIP runtime's
                                    variable: streams that share a hardware queue run one after the other, and with the
                                    default 4 a third lane's stream shares one), else 2                  [RT_AMD_LANES]      */
+    /* (struct_size >= 60) */
+    int32_t fuse_raygen;        /* the launch that traces level 0 makes the primary rays from the camera (ray_for_pixel,
+                                   src/camera.rs:37-60) as it fetches them: -1/1 yes, 0 a k_raygen launch writes them first
+                                                                                              [RT_AMD_FUSE_RAYGEN]    */
 } rt_scene_opts;
 
 /* rt_scene_create / rt_scene_create_multi with explicit switches: n_gpus = 1 and devices = {device} is

@@ -165,6 +165,9 @@ struct rt_scene {
     std::string pipe_err[PIPE_SLOTS];
     bool fuse_output = true;   // graph path: level 0's k_shade writes the shard / frame (RT_AMD_FUSE_OUTPUT=0: A/B)
     bool fuse_spawn = true;    // k_trace makes the rays of levels 1.. as it fetches them (RT_AMD_FUSE_SPAWN=0: k_spawn launches, A/B)
+    bool fuse_raygen = true;   // ... and level 0's from the camera (RT_AMD_FUSE_RAYGEN=0: a k_raygen launch writes them first, A/B)
+    const CameraParams* level0_cam = nullptr;  // set while a Camera::render frame with fuse_raygen is being enqueued
+    CameraParams* d_cam = nullptr;             // its device copy (k_set_camera), read by level 0's k_trace
     bool spawns = false;       // some leaf's material reflects or refracts: only then can a ray tree be deeper than one level
     // traversal kernels: dynamic LDS (staged BVH nodes + per-lane stacks) and the persistent grid each one gets
     size_t trav_lds_bytes = 0;
@@ -371,13 +374,23 @@ int launch_trace(rt_scene* s, hipStream_t st, const Level& L, long long n, const
                  unsigned long long* ctr, const Level& P, unsigned long long* prev, long long prev_upper, int from_parent) {
     const long long chunks = chunks_for(n) + (prev ? chunks_for(prev_upper * (s->n_lights > 0 ? s->n_lights : 1)) : 0);
     int rc = RT_OK;
+    const CameraParams* cam = s->d_cam;  // from_parent == 2: level 0's rays are made from the camera (k_set_camera) by the launch that traces them
     if (s->big) {  // overflow fix-up: one variant serves every scene class (rt_kernels.hip.h: SC_BIG)
         if (COUNT) { rt_set_error("internal: the BIG variants are not instrumented"); return RT_ERR_BAD_ARG; }
-        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_TLAS | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent);
+        return launch_trav(s, st, k_trace<SC_CSG | SC_CULL | SC_TLAS | SC_BIG, true, false>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent, cam);
+    }
+    if (from_parent == 2) {  // level 0 of a Camera::render frame, rays made from the camera: the RAYGEN variants (never instrumented)
+        if (COUNT) { rt_set_error("internal: the RAYGEN variants are not instrumented"); return RT_ERR_BAD_ARG; }
+#define RT_CALL(SC)                                                                                                                        \
+    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, false, true>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, 0, cam)    \
+                       : launch_trav(s, st, k_trace<SC, false, false, true>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, 0, cam)
+        RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
+#undef RT_CALL
+        return rc;
     }
 #define RT_CALL(SC)                                                                                                                      \
-    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent)    \
-                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent)
+    rc = s->has_smooth ? launch_trav(s, st, k_trace<SC, true, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent, cam)    \
+                       : launch_trav(s, st, k_trace<SC, false, COUNT>, chunks, s->ds, L, n, n_dev, remaining, ctr, P, prev, from_parent, cam)
     RT_BY_SCENE_CLASS(s->scene_class, RT_CALL)
 #undef RT_CALL
     return rc;
@@ -457,7 +470,8 @@ int enqueue_levels(rt_scene* s, hipStream_t st, long long n0, int D, bool sync, 
         tm.begin(stats ? &stats->ms_trace : nullptr);
         // the rays of levels 1.. are made by the k_trace that traces them, from the parent hits (RT_AMD_FUSE_SPAWN=0: by
         // k_spawn after the level before)
-        { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper, d > 0 && s->fuse_spawn); if (rc != RT_OK) return rc; }
+        const int from_parent = d > 0 ? (s->fuse_spawn ? 1 : 0) : (s->level0_cam ? 2 : 0);
+        { int rc = launch_trace<COUNT>(s, st, L, n_arg, n_dev, remaining, ctr, P, prev, prev_upper, from_parent); if (rc != RT_OK) return rc; }
         tm.end();
         if (stats) stats->n_trace_launches++;
         tm.begin(stats ? &stats->ms_queue : nullptr);
@@ -575,8 +589,9 @@ int ensure_arena(rt_scene* s, int round) {
 // While alive, the fix-up pass's own queues and counters sit in the scene's fields (and the frame's are parked).
 struct FixScope {
     rt_scene* s;
-    explicit FixScope(rt_scene* scene) : s(scene) { swap(); }
-    ~FixScope() { swap(); }
+    const CameraParams* cam;  // (the fix-up pass's level 0 holds collected rays, whatever the frame's level 0 was made from)
+    explicit FixScope(rt_scene* scene) : s(scene), cam(scene->level0_cam) { s->level0_cam = nullptr; swap(); }
+    ~FixScope() { swap(); s->level0_cam = cam; }
     void swap() {
         std::swap(s->levels, s->fix_levels);
         std::swap(s->d_counters, s->fix_d_counters);
@@ -829,7 +844,22 @@ int render_shard_impl(rt_scene* s, const rt_camera_desc* cam, const rt_render_op
     if (s->general || general_cam) return general_render(s, cam, opts, st, d_rgb, d_id, d_flags, stats, c, n_slots, n_valid, frame);
     const int D = opts->max_depth < 0 || !s->spawns ? 0 : opts->max_depth;  // see run_levels
     if ((rc = ensure_level(s, 0, n_slots)) != RT_OK || (rc = ensure_counters(s, D + 2)) != RT_OK) return rc;
-    auto raygen = [&]() { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots); };
+    const bool fused_raygen = s->fuse_raygen && !opts->want_counters;  // (the instrumented variants take their rays from k_raygen)
+    if (fused_raygen && !s->d_cam) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(CameraParams)));
+        s->allocs.push_back(p);
+        s->d_cam = static_cast<CameraParams*>(p);
+    }
+    auto raygen = [&]() {
+        if (fused_raygen) hipLaunchKernelGGL(k_set_camera, dim3(1), dim3(64), 0, st, c, s->d_cam);
+        else hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, c, s->levels[0].L, n_slots);
+    };
+    struct Level0FromCamera {  // level 0's k_trace makes its rays from `c` while this frame is being enqueued
+        rt_scene* s;
+        Level0FromCamera(rt_scene* scene, const CameraParams* cam, bool on) : s(scene) { s->level0_cam = on ? cam : nullptr; }
+        ~Level0FromCamera() { s->level0_cam = nullptr; }
+    } level0_from_camera(s, &c, fused_raygen);
     auto output = [&]() {
         hipLaunchKernelGGL(k_output, dim3(blocks_for(n_slots)), dim3(BLOCK), 0, st, s->ds, s->levels[0].L, n_slots, d_rgb, d_id, d_flags, 1, 0, c, frame ? 1 : 0);
     };
@@ -1119,6 +1149,7 @@ static int make_twin(rt_scene* s, int index) {
     t->scene_class = s->scene_class;
     t->n_lights = s->n_lights;
     t->use_graph = s->use_graph; t->fuse_output = s->fuse_output; t->fuse_spawn = s->fuse_spawn; t->spawns = s->spawns;
+    t->fuse_raygen = s->fuse_raygen;
     t->trav_lds_bytes = s->trav_lds_bytes;
     t->n_cus = s->n_cus;
     t->general = s->general;
@@ -1188,6 +1219,7 @@ namespace {
 struct Knobs {
     bool cull = true, passive = true, graph = true, device_bvh = false, verbose = false;
     bool share_meshes = true, fuse_output = true, fuse_spawn = true, tlas = true, tlas_instances = true, general = false, walk_bound = true;
+    bool fuse_raygen = true;
     int gather = -1;  // -1 automatic, 1 RCCL also for one device, 2 peer copies
     int lanes = rt_scene::PIPE_LANES;  // render lanes of rt_render_begin and its siblings
 };
@@ -1211,6 +1243,7 @@ void resolve_knobs(const rt_scene_opts* o, Knobs& k) {
     k.tlas = pick(v.top_level_tree, "RT_AMD_TLAS", true);
     k.general = pick(v.four_components, "RT_AMD_GENERAL", false);
     k.walk_bound = pick(v.walk_bound, "RT_AMD_WALK_BOUND", true);
+    k.fuse_raygen = pick(v.fuse_raygen, "RT_AMD_FUSE_RAYGEN", true);
     {   // 2: the tree, but every object left to the wavefront (no per-lane mesh instances)
         const char* e = std::getenv("RT_AMD_TLAS");
         k.tlas_instances = !(v.top_level_tree == 2 || (v.top_level_tree < 0 && e && std::atoi(e) == 2));
@@ -1450,6 +1483,7 @@ int scene_create_one(const rt_scene_desc* desc, int device, const Knobs& knobs, 
     }
     s->use_graph = knobs.graph;
     s->max_lanes = knobs.lanes;
+    s->fuse_raygen = knobs.fuse_raygen;
     s->fuse_output = knobs.fuse_output;
     s->fuse_spawn = knobs.fuse_spawn;
     *out = s;

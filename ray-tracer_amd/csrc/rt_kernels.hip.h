@@ -1330,6 +1330,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(CameraParams c, Level L, long 
     L.dx[slot] = direction.x; L.dy[slot] = direction.y; L.dz[slot] = direction.z;
 }
 
+// the camera of the frame being enqueued, for the level-0 k_trace that makes its rays from it (by value here, so that a
+// captured frame graph holds it)
+__global__ void k_set_camera(CameraParams c, CameraParams* dst) {
+    if (threadIdx.x == 0) *dst = c;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_rays_for_pixels(CameraParams c, long long n, const int32_t* __restrict__ px,
                                                            const int32_t* __restrict__ py, double* o_out, double* d_out) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1785,9 +1791,13 @@ __device__ __forceinline__ void spawn_ray(const Level& P, int tag, V3& o, V3& d)
 // its slowest 64-ray chunk (60-90 us whatever the ray count), and this way a frame pays that once per level, not
 // twice.  Either part may be empty (n_cap == 0: shadow rays only — the launch after the last level; prev_counters ==
 // null: level 0).  Every wavefront alternates between the two chunk feeds until both are dry.
-template <int SC, bool NEED_FIRST, bool COUNT>
+// RAYGEN: the variant that traces level 0 of a Camera::render frame and makes its rays from the camera (a template flag, not
+// a third value of `from_parent`: with the ray_for_pixel code in the fetch of every launch the variants of scenes with cull
+// ranges or CSG went from 33-44 to 85-94 spilled registers; this way the kernels of levels 1.. are what they were).
+template <int SC, bool NEED_FIRST, bool COUNT, bool RAYGEN = false>
 __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, long long n_cap, const unsigned long long* n_dev, int remaining,
-                                                  unsigned long long* counters, Level P, unsigned long long* prev_counters, int from_parent) {
+                                                  unsigned long long* counters, Level P, unsigned long long* prev_counters, int from_parent,
+                                                  const CameraParams* __restrict__ cam) {
     const long long n = n_cap > 0 ? level_count(n_cap, n_dev) : 0;
     const long long n_shadow = prev_counters ? (long long)prev_counters[CNT_SHADOW_Q] * S.n_lights : 0;
     if (n == 0 && n_shadow == 0) return;  // uniform over the grid: nothing staged, nothing fed
@@ -1803,7 +1813,23 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
         o = mk(dead_ray(), 0., 0.);  // padding slot / dead ray
         d = mk(0., 0., 1.);
         if (c >= 0 && i < n) {
-            if (from_parent) {
+            if (RAYGEN) {  // level 0 of Camera::render: ray_for_pixel (src/camera.rs:37-60) for the slot's pixel; no k_raygen
+                                     // launch, no pass over the level's ray columns (a padding slot stays the dead ray)
+                // The camera is read HERE, by scalar loads from its device copy (k_set_camera): as a by-value kernel argument
+                // it is loaded at the kernel's entry and its ~40 scalar registers stay live through the traversal (the variants
+                // of scenes with cull ranges went from 33 to 85 spilled registers); the opaque offset keeps the loads in place.
+                int zero = 0;
+                asm volatile("" : "+s"(zero));
+                const RT_CONSTANT CameraParams* q = as_constant(cam) + zero;
+                CameraParams cp;  // (field by field: a struct cannot be copied out of the constant address space as a whole)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) cp.inv[k] = q->inv[k];
+                cp.half_width = q->half_width; cp.half_height = q->half_height; cp.pixel_size = q->pixel_size;
+                cp.hsize = q->hsize; cp.vsize = q->vsize; cp.tiles_x = q->tiles_x; cp.tiles_y = q->tiles_y;
+                cp.rank = q->rank; cp.n_ranks = q->n_ranks;
+                int px, py;
+                if (slot_to_pixel(cp, i, px, py)) ray_for_pixel(cp, px, py, o, d);
+            } else if (from_parent) {
                 spawn_ray(P, L.hkey[i], o, d);
             } else {
                 o = mk(L.ox[i], L.oy[i], L.oz[i]);
@@ -1862,7 +1888,7 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
                 L.px[i] = point.x; L.py[i] = point.y; L.pz[i] = point.z;
                 L.nx[i] = normal_vector.x; L.ny[i] = normal_vector.y; L.nz[i] = normal_vector.z;
                 L.ht[i] = sink.best_t;
-                if (from_parent) {  // a ray made here exists nowhere else: k_walk, k_shade and the next level's spawn read a HIT's ray
+                if (!RAYGEN && from_parent) {  // a ray made here exists nowhere else: k_walk, k_shade and the next level's spawn read a HIT's ray
                     L.ox[i] = o.x; L.oy[i] = o.y; L.oz[i] = o.z;
                     L.dx[i] = d.x; L.dy[i] = d.y; L.dz[i] = d.z;
                 }
@@ -1870,6 +1896,11 @@ __global__ __launch_bounds__(TBLOCK, RT_TWAVES) void k_trace(DScene S, Level L, 
                 if ((mbits & NODE_WALKS) && needs_walk_at(S, remaining)) stage |= ST_WALK;
                 if ((mbits & NODE_REFLECTS) && remaining > 0) stage |= ST_REFLECT;      // src/world.rs:110
                 if ((mbits & NODE_REFRACTS) && remaining > 0) stage |= ST_REFRACT;      // src/world.rs:121
+            }
+            // level 0's rays made here: the overflow fix-up (k_collect_overflow) also reads a flagged ray that hit nothing
+            if (RAYGEN && (hit || (flags & RT_FLAG_LIST_OVERFLOW))) {
+                L.ox[i] = o.x; L.oy[i] = o.y; L.oz[i] = o.z;
+                L.dx[i] = d.x; L.dy[i] = d.y; L.dz[i] = d.z;
             }
             if (i < n) {
                 L.hkey[i] = key;

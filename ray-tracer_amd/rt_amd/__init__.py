@@ -248,7 +248,7 @@ class SceneOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("cull_ranges", C.c_int32), ("passive_triangles", C.c_int32), ("frame_graph", C.c_int32),
                 ("device_bvh", C.c_int32), ("gather", C.c_int32), ("verbose", C.c_int32),
                 ("share_meshes", C.c_int32), ("fuse_output", C.c_int32), ("fuse_spawn", C.c_int32), ("top_level_tree", C.c_int32),
-                ("four_components", C.c_int32), ("walk_bound", C.c_int32), ("render_lanes", C.c_int32)]
+                ("four_components", C.c_int32), ("walk_bound", C.c_int32), ("render_lanes", C.c_int32), ("fuse_raygen", C.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -1349,6 +1349,46 @@ def test_render_multi_on_distinct_devices(gather):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config", ["C3", "C4", "many"])
+def test_primary_rays_made_by_the_launch_that_traces_them_change_nothing(config):
+    """rt_scene_opts.fuse_raygen: level 0's k_trace makes the primary rays from the camera (ray_for_pixel, src/camera.rs:37-60)
+    as it fetches them, and stores only the rays something reads later, instead of a k_raygen launch writing every ray first.
+    Whole frames at full size, a shard of a 3-way split (the slot -> pixel map depends on the shard), a frame with rt_stats
+    (plain launches) and the instrumented frame (which keeps k_raygen): rgb, ids, flags and ray counts bit-identical on / off."""
+    import torch
+    build, size, depth = {"C3": (scenes.teapot_scene, (1920, 1080), 5), "C4": (scenes.mixed_scene, (1280, 720), 5),
+                          "many": (lambda wd, ht: scenes.instanced_grid(wd, ht, grid=9), (1280, 720), 4)}[config]
+    w, cam = build(*size)
+    cd = cam.desc()
+    got = {}
+    for fuse in (1, 0):
+        ms = rt.MultiScene(w, [0], fuse_raygen=fuse)
+        try:
+            out = []
+            for rank, n_ranks in ((0, 1), (1, 3)):
+                n = int(rt.lib.rt_shard_pixel_count(C.byref(cd), rank, n_ranks))
+                for want_counters, with_stats in ((0, False), (0, False), (0, True), (1, True)):   # (the second plain frame replays a graph)
+                    opts = rt.RenderOpts(max_depth=depth, rank=rank, n_ranks=n_ranks, want_counters=want_counters, stream=None)
+                    rgb = torch.full((n, 3), -1., dtype=torch.float64, device="cuda:0")
+                    ids = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+                    fl = torch.full((n,), 255, dtype=torch.uint8, device="cuda:0")
+                    torch.cuda.synchronize()
+                    st = rt.Stats()
+                    rc = rt.lib.rt_render_shard(ms.h, C.byref(cd), C.byref(opts), rgb.data_ptr(), ids.data_ptr(), fl.data_ptr(), C.byref(st) if with_stats else None)
+                    assert rc == 0, rt.last_error()
+                    out.append((rgb.cpu().numpy(), ids.cpu().numpy(), fl.cpu().numpy(),
+                                (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow, st.shaded_nodes) if with_stats else None))
+            got[fuse] = out
+        finally:
+            ms.close()
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    # every frame of one setting is the same frame, whichever path enqueued it
+    for k in (1, 2, 3):
+        assert np.array_equal(got[1][k][0], got[1][0][0], equal_nan=True) and np.array_equal(got[1][k][1], got[1][0][1])
+
+
+@pytest.mark.gpu
 def test_scene_opts_fields_switch_what_the_environment_variables_switch():
     """rt_scene_opts (rt_abi.h): every behaviour switch as a field of the ABI.  None of them may change a result: C4 (CSG,
     cull ranges, glass) and a mesh scene rendered with each switch flipped are bit-identical to the default scene, and the
@@ -1358,8 +1398,9 @@ def test_scene_opts_fields_switch_what_the_environment_variables_switch():
         ref = cam.render(w, depth=depth)
         for kw in ({"cull_ranges": 0}, {"passive_triangles": 0}, {"frame_graph": 0}, {"device_bvh": 1}, {"gather": 1},
                    {"share_meshes": 0}, {"fuse_output": 0}, {"fuse_spawn": 0}, {"top_level_tree": 0}, {"walk_bound": 0},
+                   {"fuse_raygen": 0}, {"render_lanes": 1},
                    {"cull_ranges": 0, "passive_triangles": 0, "frame_graph": 0, "device_bvh": 1, "verbose": 0, "share_meshes": 0,
-                    "fuse_output": 0, "fuse_spawn": 0}):
+                    "fuse_output": 0, "fuse_spawn": 0, "fuse_raygen": 0}):
             ms = rt.MultiScene(w, [0], **kw)
             try:
                 img = ms.render(cam, depth=depth)  # rt_render_multi (with rt_stats: plain launches)
