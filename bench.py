@@ -484,7 +484,9 @@ def main():
             t0 = time.perf_counter()
             run(n_host)
             return (time.perf_counter() - t0) / n_host * 1e3
-        host_by_depth = {d: time_rt_render_pipelined(d) for d in (4, 6)}   # 4: what two render lanes could use; 6: three lanes
+        # 4: what two render lanes could use; 6: three lanes.  --in-flight 1 (the profile scripts): one at a time here too, so that
+        # every launch of the run lasts what it lasts alone and a kernel trace's averages agree with the HIP events'
+        host_by_depth = {d: time_rt_render_pipelined(d) for d in ((4, 6) if piped else (1,))}
         host_depth = min(host_by_depth, key=host_by_depth.get)
         host_ms_pipelined = host_by_depth[host_depth]
 
