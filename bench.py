@@ -24,7 +24,9 @@ import time
 # streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other, so the
 # third render lane needs more queues than the default (include/rt_abi.h: rt_scene_opts.render_lanes).  Read by the runtime
 # when it starts: set before torch / the library are loaded; inherited by the rocprofv3 child runs.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
+_q = os.environ.get("GPU_MAX_HW_QUEUES", "")
+if os.environ.get("RT_BENCH_HW_QUEUES") or not (_q.isdigit() and int(_q) >= 6):   # (a setting that is already large enough stays)
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
