@@ -345,20 +345,17 @@ def main():
             for g in gather_done:
                 if g is not None:
                     g.synchronize()
-            for k in range(n):
-                if k >= D and rt.lib.rt_render_end(scene) < 0:
-                    raise RuntimeError(rt.last_error())
-                b = k % NB
-                if gather_done[b] is not None:
-                    gather_done[b].synchronize()      # the gather that read this buffer six frames ago
-                if rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None) < 0:
-                    raise RuntimeError(rt.last_error())
-                if k >= D:                            # (after the begin: the render lane that has just come free is busy again
-                    post((k - D) % NB)                # while this thread enqueues the gather and the scatter)
-            for k in range(max(n - D, 0), n):
-                if rt.lib.rt_render_end(scene) < 0:
-                    raise RuntimeError(rt.last_error())
-                post(k % NB)
+            for op, k, b in rt.shard_pipeline(n, D, NB):   # (the order of steps: rt_amd.shard_pipeline)
+                if op == "end":
+                    if rt.lib.rt_render_end(scene) < 0:
+                        raise RuntimeError(rt.last_error())
+                elif op == "begin":
+                    if gather_done[b] is not None:
+                        gather_done[b].synchronize()      # the gather that read this buffer six frames ago
+                    if rt.lib.rt_render_shard_begin(scene, C.byref(cd), C.byref(opts), shards[b].data_ptr(), None, None) < 0:
+                        raise RuntimeError(rt.last_error())
+                else:
+                    post(b)
             state["k"] = 0
 
         def verify():

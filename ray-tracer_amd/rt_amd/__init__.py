@@ -901,6 +901,28 @@ def shard_pixels(camera_desc, rank, n_ranks):
     return px.astype(np.int64), py.astype(np.int64), valid
 
 
+def shard_pipeline(n_frames, depth, n_buffers):
+    """The order of steps of a one-process-per-GPU driver that renders frame after frame with `depth` of its rank's shards in
+    flight (rt_render_shard_begin / rt_render_end) and `n_buffers` shard buffers used in turn; yields (step, frame, buffer):
+      "end"    rt_render_end: frame's shard is complete in its buffer
+      "begin"  rt_render_shard_begin of frame's shard into buffer — after waiting for the gather that last read that buffer
+               (frame - n_buffers, posted depth steps after its begin: n_buffers > depth makes sure it has been posted)
+      "post"   enqueue the gather (and on the root the scatter) of frame's shard; after the begin that follows its end, so that
+               the render lane that has just come free is busy again while the host enqueues the collective
+    Every rank walks the same sequence, so the collectives of all ranks match (bench.py's N > 1 path; tests/test_dist_gloo.py)."""
+    if depth < 1 or n_buffers <= depth:
+        raise ValueError("need depth >= 1 and more shard buffers than shards in flight")
+    for k in range(n_frames):
+        if k >= depth:
+            yield "end", k - depth, (k - depth) % n_buffers
+        yield "begin", k, k % n_buffers
+        if k >= depth:
+            yield "post", k - depth, (k - depth) % n_buffers
+    for k in range(max(n_frames - depth, 0), n_frames):
+        yield "end", k, k % n_buffers
+        yield "post", k, k % n_buffers
+
+
 def assemble_host(camera_desc, n_ranks, shards):
     """Host mirror of rt_assemble for tests of the gather plumbing: shards[r] is rank r's [count_r, C] array."""
     ch = shards[0].shape[1]

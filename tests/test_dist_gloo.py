@@ -61,3 +61,79 @@ def test_every_pixel_belongs_to_exactly_one_shard():
             px, py, valid = rt.shard_pixels(cd, r, world)
             np.add.at(seen, (py[valid], px[valid]), 1)
         assert np.all(seen[:100, :202] == 1) and not seen[100].any() and not seen[:, 202].any()
+
+
+def _frame_value(k, px, py):
+    """What "frame k" holds at pixel (px, py): different for every frame, so a shard buffer read too early or too late shows."""
+    return np.stack([px * 1.0 + 0.25 + 1000.0 * k, py * 2.0 + 0.5 - 7.0 * k, ((px * 31 + py * 17 + k) % 255) / 255.0], axis=1)
+
+
+def _pipeline_worker(rank, world, port, hsize, vsize, n_frames, depth, n_buffers, out_path):
+    """bench.py's N > 1 loop with shards in flight (rt_amd.shard_pipeline), rehearsed on the CPU: "rendering" a shard is
+    filling its buffer — with garbage at the begin, with the frame's values at the end, which is when the real render is
+    complete — the gather is gloo's, asynchronous like the one on bench.py's communication stream, and the root scatters
+    and checks every frame as the gather behind it is waited for."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cd = rt.Camera(hsize, vsize, math.pi / 3).desc()
+    counts = [int(rt.lib.rt_shard_pixel_count(C.byref(cd), r, world)) for r in range(world)]
+    n_max = max(counts)
+    px, py, valid = rt.shard_pixels(cd, rank, world)
+    shards = [torch.zeros((n_max, 3), dtype=torch.float64) for _ in range(n_buffers)]
+    landed = [torch.zeros((world, n_max, 3), dtype=torch.float64) if rank == 0 else None for _ in range(n_buffers)]
+    pending = [None] * n_buffers      # per shard buffer: (frame, the gather that reads it)
+    checked = []
+
+    def retire(b):
+        if pending[b] is None:
+            return
+        k, work = pending[b]
+        work.wait()
+        if rank == 0:
+            frame = rt.assemble_host(cd, world, [landed[b][r].numpy()[: counts[r]] for r in range(world)])
+            yy, xx = np.mgrid[0:vsize, 0:hsize]
+            expect = _frame_value(k, xx.reshape(-1), yy.reshape(-1)).reshape(vsize, hsize, 3)
+            expect[vsize - 1, :, :] = 0.0
+            expect[:, hsize - 1, :] = 0.0
+            assert np.array_equal(frame, expect), (k, b)
+            checked.append(k)
+        pending[b] = None
+
+    in_flight = {}
+    for op, k, b in rt.shard_pipeline(n_frames, depth, n_buffers):
+        if op == "begin":
+            retire(b)                              # the gather that last read this buffer
+            assert b not in in_flight.values() and len(in_flight) < depth + 1
+            shards[b].fill_(float("nan"))          # being rendered: nothing may read it now
+            in_flight[k] = b
+        elif op == "end":
+            assert in_flight.pop(k) == b
+            shards[b].zero_()
+            shards[b][: len(px)][valid] = torch.from_numpy(_frame_value(k, px[valid], py[valid]))
+        else:
+            assert k not in in_flight and pending[b] is None
+            work = dist.gather(shards[b], list(landed[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+            pending[b] = (k, work)
+    for b in range(n_buffers):
+        retire(b)
+    if rank == 0:
+        np.save(out_path, np.array(sorted(checked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth,n_buffers,n_frames", [(2, 3, 6, 17), (3, 2, 4, 9), (2, 1, 2, 5), (2, 3, 4, 2)])
+def test_shards_in_flight_schedule_gathers_every_frame_intact(tmp_path, world, depth, n_buffers, n_frames):
+    out = str(tmp_path / "checked.npy")
+    port = 29700 + (os.getpid() % 2000) + world * 7 + depth
+    mp.spawn(_pipeline_worker, args=(world, port, 67, 35, n_frames, depth, n_buffers, out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), np.arange(n_frames))
+
+
+def test_shard_pipeline_needs_a_free_buffer():
+    with pytest.raises(ValueError):
+        list(rt.shard_pipeline(4, 3, 3))
+    steps = list(rt.shard_pipeline(5, 2, 3))
+    assert [s for s in steps if s[0] == "begin"] == [("begin", k, k % 3) for k in range(5)]
+    assert [s[1] for s in steps if s[0] == "post"] == list(range(5)) and [s[1] for s in steps if s[0] == "end"] == list(range(5))
