@@ -232,7 +232,8 @@ typedef struct rt_stats {
      * called ms_collect / ms_shade / ms_resolve / n_shadow_launches after kernels that no longer exist — a reader of
      * the old names fails to compile instead of silently misattributing time). */
     double ms_total;
-    double ms_raygen;
+    double ms_raygen;  /* k_raygen; with rt_scene_opts.fuse_raygen (the default) level 0's k_trace makes the primary rays and
+                          this is the few microseconds of k_set_camera — ray_for_pixel's time is then part of ms_trace   */
     double ms_trace;   /* k_trace launches: closest hits of level d + the shadow rays of level d-1, one launch per level,
                           plus one for the shadow rays of the last level                                                */
     double ms_shadow;  /* always 0: the shadow rays have no launch of their own (slot kept for layout stability)        */
