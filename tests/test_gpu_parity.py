@@ -1625,6 +1625,29 @@ def test_shards_in_flight_are_the_shards_rt_render_shard_writes(monkeypatch):
     assert rt.lib.rt_render_end(scene) == 0 and rt.lib.rt_render_end(scene) == 0, rt.last_error()
     assert np.array_equal(frame.cpu().numpy(), refs[0].rgb)
     assert np.array_equal(shard.cpu().numpy(), want[1, 1][0][: shard.shape[0]])
+    # rt_assemble_strided / rt_quantise on a CALLER's stream while shards are in flight (what bench.py's N > 1 path does with the
+    # frame before): they touch none of a frame's queues, need not wait for the renders, and the shards in flight come out intact
+    side = torch.cuda.Stream()
+    n2 = [int(rt.lib.rt_shard_pixel_count(C.byref(cams[0]), r, 2)) for r in range(2)]
+    both = torch.zeros((2, max(n2), 3), dtype=torch.float64, device="cuda:0")
+    for r in range(2):
+        both[r, : n2[r]] = torch.from_numpy(want[0, r][0][: n2[r]]).to("cuda:0")
+    in_flight = [torch.full((max(n2), 3), -1., dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    assembled = torch.full((cam.vsize, cam.hsize, 3), -1., dtype=torch.float64, device="cuda:0")
+    q = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for k in range(3):
+        ok = rt.RenderOpts(max_depth=5, rank=k & 1, n_ranks=2, want_counters=0, stream=None)
+        assert rt.lib.rt_render_shard_begin(scene, C.byref(cams[1]), C.byref(ok), in_flight[k].data_ptr(), None, None) == 0, rt.last_error()
+    cs = C.c_void_p(side.cuda_stream)
+    assert rt.lib.rt_assemble_strided(scene, C.byref(cams[0]), 2, both.data_ptr(), None, max(n2), assembled.data_ptr(), None, cs) == 0, rt.last_error()
+    assert rt.lib.rt_quantise(scene, assembled.data_ptr(), cam.vsize * cam.hsize * 3, q.data_ptr(), cs) == 0, rt.last_error()
+    side.synchronize()
+    assert np.array_equal(assembled.cpu().numpy(), refs[0].rgb)
+    assert np.array_equal(q.cpu().numpy(), refs[0].quantised().astype(np.uint8))
+    for k in range(3):
+        assert rt.lib.rt_render_end(scene) == 0, rt.last_error()
+        assert np.array_equal(in_flight[k].cpu().numpy()[: n2[k & 1]], want[1, k & 1][0][: n2[k & 1]]), k
     bad = rt.RenderOpts(max_depth=5, rank=2, n_ranks=2, want_counters=0, stream=None)
     assert rt.lib.rt_render_shard_begin(scene, C.byref(cams[0]), C.byref(bad), shard.data_ptr(), None, None) == rt.RT_ERR_BAD_ARG
     assert rt.lib.rt_render_frame_begin(scene, C.byref(cams[0]), C.byref(o), frame.data_ptr(), None, None) == rt.RT_ERR_BAD_ARG
